@@ -1,0 +1,163 @@
+/*
+ * pgtwin.h — C-ABI of libpgtwin: the MI355X (gfx950) window-scan engine that replaces the
+ * per-window reduction of PopGenomicsTools' fstWindow / hetWindow / dxyWindow.
+ *
+ * The reference has no FFI or plugin interface; the seam this library replaces is the
+ * function `calcWindow` and the bookkeeping around its call sites (file:line in the reference):
+ *     fstWindow.cpp:69-107   called from fstWindow.cpp:134,137,151
+ *     hetWindow.cpp:66-105   called from hetWindow.cpp:132,135,149
+ *     dxyWindow.cpp:172-209  called from dxyWindow.cpp:346,354,358,366,377,416,425
+ * The reference calls it once per window on a W-entry buffer it owns and re-sums; this library
+ * is called once per input: the host describes every window as a range [lo,hi) of the global
+ * site index (pgt_build_windows_*), and the device reduces all of them from structure-of-arrays
+ * columns resident in HBM (pgt_*_reduce*).
+ *
+ * Conventions
+ *   - plain C types only; every function returns PGT_OK (0) or a PGT_E* code; the message is
+ *     retrievable with pgt_last_error(ctx) (ctx may be NULL for the ctx-less functions);
+ *     the reference's tools exit 255 on error (`return -1`, fstWindow.cpp:42,48,55) and the
+ *     retained C++ hosts do the same after printing that message;
+ *   - the caller owns every buffer; the library retains nothing past return;
+ *   - one pgt_ctx per GPU and per thread (one process per GPU); a ctx is not thread-safe;
+ *   - there is NO CPU fallback: without a usable gfx950 device pgt_open fails.
+ */
+#ifndef PGTWIN_H
+#define PGTWIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGT_ABI_VERSION 1
+
+enum {
+    PGT_OK = 0,
+    PGT_EARG = 1,     /* bad argument (NULL, S>W, misaligned device pointer, ...) */
+    PGT_ECAP = 2,     /* output capacity too small; *n_out holds the required count */
+    PGT_EDEVICE = 3,  /* HIP error / no gfx950 device */
+    PGT_EDOMAIN = 4,  /* input outside the reference's defined domain */
+    PGT_ENOMEM = 5
+};
+
+typedef struct pgt_ctx pgt_ctx;
+
+/* One window = one call of the reference's calcWindow.
+ * flags bit0 (PGT_WIN_COORDS): start/end are given here (dxy bp mode: bp-slot coordinates,
+ * dxyWindow.cpp:347,367,389); otherwise the reduce fills them from pos[lo], pos[hi-1]
+ * (fstWindow.cpp:71-72). */
+#define PGT_WIN_COORDS 1u
+typedef struct {
+    uint64_t lo, hi;    /* global site index range [lo,hi) reduced by this window; lo==hi allowed */
+    uint32_t label_run; /* chromosome run whose name labels the row */
+    uint32_t flags;
+    uint32_t start, end;
+} pgt_win;
+
+typedef struct { /* fstWindow.cpp:88 row: chr start end mid fst nsites */
+    uint32_t start, end, mid, n;
+    double fst;        /* bsum != 0 ? asum/bsum : 0   (fstWindow.cpp:85) */
+    double asum, bsum; /* the two window sums, full precision */
+} pgt_fst_row;
+
+typedef struct { /* hetWindow.cpp:87 row: chr start end mid h nonmissing */
+    uint32_t start, end, mid, nonmissing;
+    uint32_t nhet, pad_;
+    double h; /* nonmissing ? nhet/nonmissing : 0   (hetWindow.cpp:84) */
+} pgt_het_row;
+
+typedef struct { /* dxyWindow.cpp:190 row: chr start end dxy neffective nskip */
+    uint32_t start, end, neff, nskip;
+    double sum;
+} pgt_dxy_row;
+
+typedef struct { /* dxyWindow.cpp:429-433 genome-wide line */
+    double sum;
+    uint64_t neff, nskip;
+} pgt_dxy_total;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* device: HIP ordinal, or -1 for the current device.  Fails (NULL, message via
+ * pgt_last_error(NULL)) when no HIP device is usable. */
+pgt_ctx *pgt_open(int device);
+void pgt_close(pgt_ctx *ctx);
+const char *pgt_last_error(const pgt_ctx *ctx);
+int pgt_abi_version(void);
+
+/* ---- window tables (host, O(#windows + #runs), no device needed) ------------------------ */
+/* Site-count windows of fstWindow / hetWindow / dxyWindow -fixedsite 1: the emission rules of
+ * fstWindow.cpp:132-138,150-152 applied to the chromosome run lengths (run_len[r] = number of
+ * consecutive sites carrying the same chromosome name).  Requires 1 <= S <= W (Q9).
+ * out may be NULL (count only).  Returns PGT_ECAP when cap < *n_out. */
+int pgt_build_windows_sites(const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S,
+                            pgt_win *out, size_t cap, size_t *n_out);
+
+/* Base-pair windows of dxyWindow (-fixedsite 0): the slot machine of dxyWindow.cpp:334-378,
+ * 407-426 over bp slots 1..chr_len of every run; pos (host pointer, n sites, strictly
+ * increasing inside a run) locates the data sites of each window.  chr_len[r] is the -sizefile
+ * length of run r's chromosome.  Rows carry PGT_WIN_COORDS. */
+int pgt_build_windows_bp(const uint32_t *pos, const uint64_t *run_len, const uint32_t *chr_len,
+                         size_t n_runs, uint32_t W, uint32_t S, pgt_win *out, size_t cap,
+                         size_t *n_out);
+
+/* ---- reductions, host buffers (copy in, reduce on the GPU, copy out; synchronous) ------- */
+int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
+                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out);
+int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n,
+                   const pgt_win *win, uint64_t n_win, pgt_het_row *out);
+/* tot may be NULL.  n_win may be 0 (global only: dxyWindow -winsize 0 -fixedsite 1). */
+int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
+                   const int32_t *n1, const int32_t *n2, uint64_t n, int minind,
+                   const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot);
+
+/* ---- reductions, device-resident columns (asynchronous on `stream`) --------------------- */
+/* Every pointer is a DEVICE pointer on ctx's device; f64 columns must be 16-byte aligned.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  `tree` is caller
+ * workspace of at least pgt_tree_bytes(stat, n) bytes, 256-byte aligned: it receives the
+ * radix-64 range tree and may be reused by later calls. */
+enum { PGT_STAT_FST = 0, PGT_STAT_HET = 1, PGT_STAT_DXY = 2 };
+size_t pgt_tree_bytes(int stat, uint64_t n_sites);
+
+int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b,
+                       uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
+                       void *tree, size_t tree_bytes, void *stream);
+int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n,
+                       const pgt_win *win, uint64_t n_win, pgt_het_row *out, void *tree,
+                       size_t tree_bytes, void *stream);
+/* tot: device pointer to one pgt_dxy_total, or NULL. */
+int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
+                       const int32_t *n1, const int32_t *n2, uint64_t n, int minind,
+                       const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
+                       void *tree, size_t tree_bytes, void *stream);
+
+/* Batched population pairs sharing one position column and one window table (BASELINE
+ * config 5): a[p], b[p] are HOST arrays of n_pairs DEVICE column pointers; out holds
+ * n_pairs * n_win rows, pair-major; tree holds n_pairs trees (n_pairs * pgt_tree_bytes). */
+int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *a,
+                             const double *const *b, uint32_t n_pairs, uint64_t n,
+                             const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
+                             size_t tree_bytes, void *stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream; for bench.py's roofline) ------- */
+/* When enabled, the *_dev entry points bracket the tree-build kernel and the window-query
+ * kernel with HIP events; pgt_last_kernel_ms synchronises on them and returns both. */
+int pgt_set_profiling(pgt_ctx *ctx, int enabled);
+int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms);
+
+/* ---- multi-GPU sharding plan (host) ----------------------------------------------------- */
+/* Split a window table into n_ranks contiguous blocks balanced by reduced sites.  Rank r owns
+ * windows [win_begin, win_end) and needs the site columns [site_lo, site_hi); site_lo is
+ * rounded down to a multiple of 65536 so that every rank's range tree has the same node
+ * boundaries as the single-GPU tree (results are then bitwise independent of n_ranks). */
+typedef struct {
+    uint64_t win_begin, win_end;
+    uint64_t site_lo, site_hi;
+} pgt_shard;
+int pgt_plan_shards(const pgt_win *win, uint64_t n_win, uint32_t n_ranks, pgt_shard *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGTWIN_H */

@@ -1,0 +1,583 @@
+/*
+ * window_oracle.c — CPU restatement of the reference's streaming window scan.
+ * TEST INFRASTRUCTURE ONLY (see window_oracle.h for scope, citations and how it is pinned).
+ *
+ * Shape of the algorithm (the reference's, not the product's):
+ *   - one W-entry buffer, filled site by site;
+ *   - a window is emitted (i) when a site of a new chromosome arrives and the buffer is
+ *     non-empty, (ii) when the buffer is full and another site arrives, (iii) at end of input
+ *     if W-S < fill <= W;
+ *   - every emission re-sums the whole buffer sequentially in double precision, then keeps
+ *     the last W-S entries if (and only if) the buffer was full, else empties it.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "window_oracle.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * The W-entry buffer.  Columns are kept side by side; which ones are live depends on the tool.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t W, S, fill;
+    uint32_t *coord; /* printed coordinate of the entry (site position or bp slot) */
+    int64_t *site;   /* global data-site index, -1 for a dxy placeholder slot */
+    double *x;       /* fst: a      dxy: per-site value (>=0, -9 skipped, -7 placeholder) */
+    double *y;       /* fst: b */
+    int32_t *g;      /* het: genotype */
+} wbuf;
+
+typedef struct {
+    orc_row *rows;
+    size_t cap, count;
+} sink;
+
+static int wbuf_init(wbuf *wb, uint32_t W, uint32_t S) {
+    memset(wb, 0, sizeof *wb);
+    wb->W = W;
+    wb->S = S;
+    size_t m = W ? W : 1;
+    wb->coord = calloc(m, sizeof *wb->coord);
+    wb->site = calloc(m, sizeof *wb->site);
+    wb->x = calloc(m, sizeof *wb->x);
+    wb->y = calloc(m, sizeof *wb->y);
+    wb->g = calloc(m, sizeof *wb->g);
+    return (wb->coord && wb->site && wb->x && wb->y && wb->g) ? 0 : -1;
+}
+
+static void wbuf_free(wbuf *wb) {
+    free(wb->coord);
+    free(wb->site);
+    free(wb->x);
+    free(wb->y);
+    free(wb->g);
+}
+
+/* fstWindow.cpp:91-105 / hetWindow.cpp:90-103 / dxyWindow.cpp:194-207: a full buffer keeps its
+ * last W-S entries ("same chromosome"), anything else is emptied ("new chromosome"). */
+static void wbuf_advance(wbuf *wb) {
+    if (wb->fill == wb->W) {
+        uint32_t keep = wb->W - wb->S;
+        memmove(wb->coord, wb->coord + wb->S, keep * sizeof *wb->coord);
+        memmove(wb->site, wb->site + wb->S, keep * sizeof *wb->site);
+        memmove(wb->x, wb->x + wb->S, keep * sizeof *wb->x);
+        memmove(wb->y, wb->y + wb->S, keep * sizeof *wb->y);
+        memmove(wb->g, wb->g + wb->S, keep * sizeof *wb->g);
+        wb->fill = keep;
+    } else {
+        wb->fill = 0;
+    }
+}
+
+static void site_range(const wbuf *wb, uint64_t *lo, uint64_t *hi) {
+    int64_t first = -1, last = -1;
+    for (uint32_t i = 0; i < wb->fill; ++i)
+        if (wb->site[i] >= 0) {
+            if (first < 0) first = wb->site[i];
+            last = wb->site[i];
+        }
+    *lo = first < 0 ? 0 : (uint64_t)first;
+    *hi = first < 0 ? 0 : (uint64_t)last + 1;
+}
+
+static orc_row *sink_next(sink *sk) {
+    static orc_row scratch;
+    orc_row *r = sk->count < sk->cap ? &sk->rows[sk->count] : &scratch;
+    sk->count++;
+    memset(r, 0, sizeof *r);
+    r->printed = 1;
+    return r;
+}
+
+/* fstWindow.cpp:69-107 */
+static void fst_emit(wbuf *wb, uint32_t label, sink *sk) {
+    orc_row *r = sink_next(sk);
+    uint32_t n = wb->fill;
+    r->label = label;
+    r->start = wb->coord[0];
+    r->end = wb->coord[n - 1];
+    r->mid = (uint32_t)(r->start + r->end) / 2u; /* unsigned wrap kept on purpose (:73) */
+    double asum = 0.0, bsum = 0.0;
+    for (uint32_t i = 0; i < n; ++i) { /* :80-83 sequential, re-done per window */
+        asum += wb->x[i];
+        bsum += wb->y[i];
+    }
+    r->num = asum;
+    r->den = bsum;
+    r->value = bsum != 0.0 ? asum / bsum : 0.0; /* :85 */
+    r->n = n;
+    site_range(wb, &r->lo, &r->hi);
+    wbuf_advance(wb);
+}
+
+/* hetWindow.cpp:66-105 */
+static void het_emit(wbuf *wb, uint32_t label, sink *sk) {
+    orc_row *r = sink_next(sk);
+    uint32_t n = wb->fill;
+    r->label = label;
+    r->start = wb->coord[0];
+    r->end = wb->coord[n - 1];
+    r->mid = (uint32_t)(r->start + r->end) / 2u;
+    uint32_t nonmissing = 0, nhet = 0;
+    for (uint32_t i = 0; i < n; ++i) /* :77-82 */
+        if (wb->g[i] >= 0) {
+            ++nonmissing;
+            if (wb->g[i] == 1) ++nhet;
+        }
+    r->num = nhet;
+    r->den = nonmissing;
+    r->value = nonmissing != 0 ? (double)nhet / nonmissing : 0.0; /* :84 */
+    r->n = nonmissing;                                             /* column 6 is nonmissing (:87) */
+    site_range(wb, &r->lo, &r->hi);
+    wbuf_advance(wb);
+}
+
+/* dxyWindow.cpp:172-209 */
+static void dxy_emit(wbuf *wb, uint32_t label, int skip_missing, sink *sk) {
+    orc_row *r = sink_next(sk);
+    uint32_t n = wb->fill;
+    double sum = 0.0;
+    uint32_t neff = 0, nskip = 0;
+    for (uint32_t i = 0; i < n; ++i) { /* :179-186 */
+        if (wb->x[i] >= 0) {
+            sum += wb->x[i];
+            ++neff;
+        } else if (wb->x[i] == -9) {
+            ++nskip;
+        }
+    }
+    r->label = label;
+    r->start = wb->coord[0];
+    r->end = wb->coord[n - 1];
+    r->mid = 0;
+    r->value = r->num = sum;
+    r->n = neff;
+    r->nskip = nskip;
+    r->printed = (neff > 0 || !skip_missing) ? 1u : 0u; /* :189 */
+    site_range(wb, &r->lo, &r->hi);
+    wbuf_advance(wb);
+}
+
+static int check_ws(uint32_t W, uint32_t S) { return (W >= 1 && S >= 1 && S <= W) ? 0 : -1; }
+
+int orc_fst_scan(const uint32_t *chr, const uint32_t *pos, const double *a, const double *b, size_t n,
+                 uint32_t W, uint32_t S, orc_row *out, size_t cap, size_t *n_out) {
+    if (check_ws(W, S) || !n_out) return ORC_EARG;
+    wbuf wb;
+    if (wbuf_init(&wb, W, S)) return ORC_EIO;
+    sink sk = {out, cap, 0};
+    uint32_t run = 0;
+    for (size_t i = 0; i < n; ++i) { /* fstWindow.cpp:125-147 */
+        int newchr = i > 0 && chr[i] != chr[i - 1];
+        if (newchr && wb.fill > 0) fst_emit(&wb, run, &sk);            /* :132-134, label = old chr */
+        else if (wb.fill == W) fst_emit(&wb, run + (uint32_t)newchr, &sk); /* :135-138, label = chr  */
+        if (newchr) ++run;
+        uint32_t k = wb.fill++; /* :141-143 */
+        wb.coord[k] = pos[i];
+        wb.site[k] = (int64_t)i;
+        wb.x[k] = a[i];
+        wb.y[k] = b[i];
+    }
+    if (wb.fill > W - S && wb.fill <= W) fst_emit(&wb, run, &sk); /* :150-152 */
+    wbuf_free(&wb);
+    *n_out = sk.count;
+    return sk.count > cap ? ORC_ECAP : ORC_OK;
+}
+
+int orc_het_scan(const uint32_t *chr, const uint32_t *pos, const int32_t *g, size_t n, uint32_t W,
+                 uint32_t S, orc_row *out, size_t cap, size_t *n_out) {
+    if (check_ws(W, S) || !n_out) return ORC_EARG;
+    wbuf wb;
+    if (wbuf_init(&wb, W, S)) return ORC_EIO;
+    sink sk = {out, cap, 0};
+    uint32_t run = 0;
+    for (size_t i = 0; i < n; ++i) { /* hetWindow.cpp:123-145 */
+        int newchr = i > 0 && chr[i] != chr[i - 1];
+        if (newchr && wb.fill > 0) het_emit(&wb, run, &sk);
+        else if (wb.fill == W) het_emit(&wb, run + (uint32_t)newchr, &sk);
+        if (newchr) ++run;
+        uint32_t k = wb.fill++;
+        wb.coord[k] = pos[i];
+        wb.site[k] = (int64_t)i;
+        wb.g[k] = g[i];
+    }
+    if (wb.fill > W - S && wb.fill <= W) het_emit(&wb, run, &sk); /* :148-150 */
+    wbuf_free(&wb);
+    *n_out = sk.count;
+    return sk.count > cap ? ORC_ECAP : ORC_OK;
+}
+
+static void dxy_push(wbuf *wb, uint32_t coord, double v, int64_t site) {
+    uint32_t k = wb->fill++;
+    wb->coord[k] = coord;
+    wb->x[k] = v;
+    wb->site[k] = site;
+}
+
+int orc_dxy_scan(const uint32_t *chr, const uint32_t *pos, const double *p1, const double *p2,
+                 const int32_t *n1, const int32_t *n2, size_t n, uint32_t W, uint32_t S, int minind,
+                 int fixedsite, int skip_missing, const uint32_t *run_chr_len, size_t n_runs,
+                 orc_row *out, size_t cap, size_t *n_out, orc_dxy_total *tot) {
+    if (!n_out || !tot) return ORC_EARG;
+    if (W > 0 && check_ws(W, S)) return ORC_EARG; /* dxyWindow.cpp:128-131 + Q9 */
+    if (W == 0 && !fixedsite) return ORC_EDOMAIN; /* Q10: the reference indexes an empty vector */
+    if (!fixedsite && !run_chr_len) return ORC_EARG;
+    if (n == 0) return ORC_EDOMAIN; /* the reference reads a first site unconditionally (:285-292) */
+    wbuf wb;
+    if (wbuf_init(&wb, W, S)) return ORC_EIO;
+    sink sk = {out, cap, 0};
+    uint32_t run = 0, positer = 1;
+    double gsum = 0.0;
+    uint32_t gneff = 0, gskip = 0;
+
+    for (size_t i = 0; i < n; ++i) { /* dxyWindow.cpp:313-404 */
+        int newchr = i > 0 && chr[i] != chr[i - 1];
+        if (W > 0 && newchr) { /* :334-361 */
+            if (!fixedsite) {
+                if (run >= n_runs) { wbuf_free(&wb); return ORC_EARG; }
+                uint32_t lastpos = run_chr_len[run];
+                while (positer <= lastpos) { /* :345-352 pad the old chromosome to its length */
+                    if (wb.fill == W) dxy_emit(&wb, run, skip_missing, &sk);
+                    dxy_push(&wb, positer, -7.0, -1);
+                    ++positer;
+                }
+                if (wb.fill > W - S) dxy_emit(&wb, run, skip_missing, &sk); /* :353-355 */
+            } else if (wb.fill > 0) {
+                dxy_emit(&wb, run, skip_missing, &sk); /* :358 */
+            }
+            positer = 1; /* :360 */
+        }
+        if (newchr) ++run;
+        if (W > 0 && !fixedsite) { /* :363-373 placeholders up to the data site */
+            while (positer < pos[i]) {
+                if (wb.fill == W) dxy_emit(&wb, run, skip_missing, &sk);
+                dxy_push(&wb, positer, -7.0, -1);
+                ++positer;
+            }
+        }
+        if (W > 0 && wb.fill == W) dxy_emit(&wb, run, skip_missing, &sk); /* :376-378 */
+
+        double d = (n1[i] >= minind && n2[i] >= minind)
+                       ? p1[i] * (1.0 - p2[i]) + p2[i] * (1.0 - p1[i])
+                       : -9.0; /* :381 */
+        if (d != -9.0) {       /* :382-385 */
+            gsum += d;
+            ++gneff;
+        } else {
+            ++gskip;
+        }
+        if (W > 0) { /* :388-394 */
+            dxy_push(&wb, pos[i], d, (int64_t)i);
+            ++positer;
+        }
+    }
+    if (W > 0 && !fixedsite) { /* :407-423 */
+        if (run >= n_runs) { wbuf_free(&wb); return ORC_EARG; }
+        uint32_t lastpos = run_chr_len[run];
+        while (positer <= lastpos) {
+            if (wb.fill == W) dxy_emit(&wb, run, skip_missing, &sk);
+            dxy_push(&wb, positer, -7.0, -1);
+            ++positer;
+        }
+    }
+    if (W > 0 && wb.fill > W - S && wb.fill <= W) dxy_emit(&wb, run, skip_missing, &sk); /* :424-426 */
+    tot->sum = gsum;
+    tot->neff = gneff;
+    tot->nskip = gskip;
+    wbuf_free(&wb);
+    *n_out = sk.count;
+    return sk.count > cap ? ORC_ECAP : ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Text front ends
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    size_t n, cap;
+    uint32_t *chr, *pos;
+    double *x, *y;
+    int32_t *g, *k;
+    size_t n_runs, runs_cap;
+    char **run_name;
+} table;
+
+static void table_free(table *t) {
+    free(t->chr); free(t->pos); free(t->x); free(t->y); free(t->g); free(t->k);
+    for (size_t i = 0; i < t->n_runs; ++i) free(t->run_name[i]);
+    free(t->run_name);
+    memset(t, 0, sizeof *t);
+}
+
+static int table_grow(table *t) {
+    if (t->n < t->cap) return 0;
+    size_t c = t->cap ? t->cap * 2 : 4096;
+    uint32_t *chr = realloc(t->chr, c * sizeof *chr); if (!chr) return -1; t->chr = chr;
+    uint32_t *pos = realloc(t->pos, c * sizeof *pos); if (!pos) return -1; t->pos = pos;
+    double *x = realloc(t->x, c * sizeof *x); if (!x) return -1; t->x = x;
+    double *y = realloc(t->y, c * sizeof *y); if (!y) return -1; t->y = y;
+    int32_t *g = realloc(t->g, c * sizeof *g); if (!g) return -1; t->g = g;
+    int32_t *k = realloc(t->k, c * sizeof *k); if (!k) return -1; t->k = k;
+    t->cap = c;
+    return 0;
+}
+
+static int table_run(table *t, const char *name, size_t len) {
+    if (t->n_runs && strlen(t->run_name[t->n_runs - 1]) == len &&
+        memcmp(t->run_name[t->n_runs - 1], name, len) == 0)
+        return 0;
+    if (t->n_runs == t->runs_cap) {
+        size_t c = t->runs_cap ? t->runs_cap * 2 : 64;
+        char **r = realloc(t->run_name, c * sizeof *r);
+        if (!r) return -1;
+        t->run_name = r;
+        t->runs_cap = c;
+    }
+    char *s = malloc(len + 1);
+    if (!s) return -1;
+    memcpy(s, name, len);
+    s[len] = 0;
+    t->run_name[t->n_runs++] = s;
+    return 0;
+}
+
+static const char *skip_ws(const char *p) {
+    while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
+    return p;
+}
+static const char *skip_tok(const char *p) {
+    while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;
+    return p;
+}
+
+/* kind: 0 = "chr pos a b" (fst), 1 = "chr pos g" (het), 2 = ANGSD mafs with header
+ * "chr pos major minor ref freq nind" (dxyWindow.cpp:141-153).  Reading stops at the first
+ * empty line like the reference loop condition (fstWindow.cpp:125), or at EOF. */
+static int table_read(const char *path, int kind, table *t) {
+    memset(t, 0, sizeof *t);
+    FILE *f = fopen(path, "r");
+    if (!f) return ORC_EIO;
+    char *line = NULL;
+    size_t lcap = 0;
+    ssize_t len;
+    int rc = ORC_OK;
+    if (kind == 2 && getline(&line, &lcap, f) < 0) { /* header (dxyWindow.cpp:284) */
+        rc = ORC_EDOMAIN;
+        goto done;
+    }
+    while ((len = getline(&line, &lcap, f)) >= 0) {
+        const char *p = skip_ws(line);
+        if (*p == '\n' || *p == 0) break;
+        const char *e = skip_tok(p);
+        if (table_grow(t) || table_run(t, p, (size_t)(e - p))) { rc = ORC_EIO; goto done; }
+        size_t i = t->n;
+        t->chr[i] = (uint32_t)(t->n_runs - 1);
+        char *q;
+        t->pos[i] = (uint32_t)strtoul(e, &q, 10);
+        if (kind == 0) {
+            t->x[i] = strtod(q, &q);
+            t->y[i] = strtod(q, &q);
+        } else if (kind == 1) {
+            t->g[i] = (int32_t)strtol(q, &q, 10);
+        } else {
+            const char *c = q;
+            for (int skip = 0; skip < 3; ++skip) c = skip_tok(skip_ws(c)); /* major minor ref */
+            t->x[i] = strtod(c, &q);
+            t->k[i] = (int32_t)strtol(q, &q, 10);
+        }
+        t->n++;
+    }
+done:
+    free(line);
+    fclose(f);
+    if (rc != ORC_OK) table_free(t);
+    return rc;
+}
+
+static int rows_alloc(size_t n, uint32_t S, size_t extra, orc_row **rows, size_t *cap) {
+    *cap = n / (S ? S : 1) + extra + 8;
+    *rows = malloc(*cap * sizeof **rows);
+    return *rows ? 0 : -1;
+}
+
+int orc_fst_text(const char *path, uint32_t W, uint32_t S, FILE *out) {
+    if (check_ws(W, S)) return ORC_EARG;
+    table t;
+    int rc = table_read(path, 0, &t);
+    if (rc) return rc;
+    orc_row *rows;
+    size_t cap, nr = 0;
+    if (rows_alloc(t.n, S, t.n_runs, &rows, &cap)) { table_free(&t); return ORC_EIO; }
+    rc = orc_fst_scan(t.chr, t.pos, t.x, t.y, t.n, W, S, rows, cap, &nr);
+    if (rc == ORC_OK)
+        for (size_t i = 0; i < nr; ++i) /* fstWindow.cpp:88, default ostream precision == %g */
+            fprintf(out, "%s\t%u\t%u\t%u\t%g\t%u\n", t.run_name[rows[i].label], rows[i].start,
+                    rows[i].end, rows[i].mid, rows[i].value, rows[i].n);
+    free(rows);
+    table_free(&t);
+    return rc;
+}
+
+int orc_het_text(const char *path, uint32_t W, uint32_t S, FILE *out) {
+    if (check_ws(W, S)) return ORC_EARG;
+    table t;
+    int rc = table_read(path, 1, &t);
+    if (rc) return rc;
+    orc_row *rows;
+    size_t cap, nr = 0;
+    if (rows_alloc(t.n, S, t.n_runs, &rows, &cap)) { table_free(&t); return ORC_EIO; }
+    rc = orc_het_scan(t.chr, t.pos, t.g, t.n, W, S, rows, cap, &nr);
+    if (rc == ORC_OK)
+        for (size_t i = 0; i < nr; ++i) /* hetWindow.cpp:87 */
+            fprintf(out, "%s\t%u\t%u\t%u\t%g\t%u\n", t.run_name[rows[i].label], rows[i].start,
+                    rows[i].end, rows[i].mid, rows[i].value, rows[i].n);
+    free(rows);
+    table_free(&t);
+    return rc;
+}
+
+int orc_dxy_text(const char *maf1, const char *maf2, const char *sizefile, uint32_t W, uint32_t S,
+                 int minind, int fixedsite, int skip_missing, FILE *out, FILE *err) {
+    table t1, t2;
+    int rc = table_read(maf1, 2, &t1);
+    if (rc) return rc;
+    rc = table_read(maf2, 2, &t2);
+    if (rc) { table_free(&t1); return rc; }
+    uint32_t *run_len = NULL;
+    orc_row *rows = NULL;
+    /* identical site sets only: the sole input class on which dxyWindow.cpp:315-331 is defined */
+    if (t1.n != t2.n || t1.n_runs != t2.n_runs) { rc = ORC_EDOMAIN; goto done; }
+    for (size_t r = 0; r < t1.n_runs; ++r)
+        if (strcmp(t1.run_name[r], t2.run_name[r])) { rc = ORC_EDOMAIN; goto done; }
+    for (size_t i = 0; i < t1.n; ++i)
+        if (t1.pos[i] != t2.pos[i] || t1.chr[i] != t2.chr[i]) { rc = ORC_EDOMAIN; goto done; }
+
+    uint64_t slots = 0;
+    if (!fixedsite) { /* dxyWindow.cpp:155-170 + :338-343 */
+        if (!sizefile) { rc = ORC_EARG; goto done; }
+        run_len = calloc(t1.n_runs ? t1.n_runs : 1, sizeof *run_len);
+        FILE *sf = fopen(sizefile, "r");
+        if (!sf || !run_len) { if (sf) fclose(sf); rc = ORC_EIO; goto done; }
+        char name[4096];
+        unsigned len;
+        while (fscanf(sf, "%4095s %u", name, &len) == 2)
+            for (size_t r = 0; r < t1.n_runs; ++r)
+                if (!run_len[r] && !strcmp(name, t1.run_name[r])) run_len[r] = len; /* map::insert keeps the first */
+        fclose(sf);
+        for (size_t r = 0; r < t1.n_runs; ++r) {
+            if (!run_len[r]) { rc = ORC_EDOMAIN; goto done; }
+            slots += run_len[r];
+        }
+    }
+    size_t cap, nr = 0;
+    if (rows_alloc((size_t)(fixedsite ? t1.n : slots + t1.n), S, 2 * t1.n_runs, &rows, &cap)) { rc = ORC_EIO; goto done; }
+    orc_dxy_total tot;
+    rc = orc_dxy_scan(t1.chr, t1.pos, t1.x, t2.x, t1.k, t2.k, t1.n, W, S, minind, fixedsite,
+                      skip_missing, run_len, t1.n_runs, rows, cap, &nr, &tot);
+    if (rc == ORC_OK) {
+        for (size_t i = 0; i < nr; ++i)
+            if (rows[i].printed) /* dxyWindow.cpp:190 */
+                fprintf(out, "%s\t%u\t%u\t%g\t%u\t%u\n", t1.run_name[rows[i].label], rows[i].start,
+                        rows[i].end, rows[i].value, rows[i].n, rows[i].nskip);
+        fprintf(W == 0 ? out : err, "%g\t%u\t%u\n", tot.sum, tot.neff, tot.nskip); /* :429-433 */
+    }
+done:
+    free(rows);
+    free(run_len);
+    table_free(&t1);
+    table_free(&t2);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Fast writers for synthetic text inputs (values are multiples of 1e-6, as ANGSD text is)
+ * ---------------------------------------------------------------------------------------- */
+static char *put_u32(char *p, uint32_t v) {
+    char tmp[10];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+static char *put_fixed6(char *p, double v) {
+    double s = v * 1e6;
+    long long k = llround(s);
+    if (fabs(s - (double)k) > 1e-3 || fabs(v) > 4e3) return p + sprintf(p, "%.17g", v);
+    if (signbit(v)) { *p++ = '-'; k = -k; } /* also "-0.000000", as printf("%.6f") prints it */
+    p = put_u32(p, (uint32_t)(k / 1000000));
+    uint32_t frac = (uint32_t)(k % 1000000);
+    *p++ = '.';
+    for (int d = 100000; d; d /= 10) { *p++ = (char)('0' + frac / d); frac %= d; }
+    return p;
+}
+
+int orc_write_fst_text(const char *path, const uint32_t *chr, const uint32_t *pos, const double *a,
+                       const double *b, size_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return ORC_EIO;
+    static char buf[1 << 16];
+    setvbuf(f, buf, _IOFBF, sizeof buf);
+    char line[160];
+    for (size_t i = 0; i < n; ++i) {
+        char *p = line;
+        memcpy(p, "chr", 3); p += 3;
+        p = put_u32(p, chr[i] + 1); *p++ = '\t';
+        p = put_u32(p, pos[i]); *p++ = '\t';
+        p = put_fixed6(p, a[i]); *p++ = '\t';
+        p = put_fixed6(p, b[i]); *p++ = '\n';
+        fwrite(line, 1, (size_t)(p - line), f);
+    }
+    return fclose(f) ? ORC_EIO : ORC_OK;
+}
+
+int orc_write_het_text(const char *path, const uint32_t *chr, const uint32_t *pos, const int32_t *g,
+                       size_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return ORC_EIO;
+    static char buf[1 << 16];
+    setvbuf(f, buf, _IOFBF, sizeof buf);
+    char line[96];
+    for (size_t i = 0; i < n; ++i) {
+        char *p = line;
+        memcpy(p, "chr", 3); p += 3;
+        p = put_u32(p, chr[i] + 1); *p++ = '\t';
+        p = put_u32(p, pos[i]); *p++ = '\t';
+        if (g[i] < 0) { *p++ = '-'; p = put_u32(p, (uint32_t)(-g[i])); }
+        else p = put_u32(p, (uint32_t)g[i]);
+        *p++ = '\n';
+        fwrite(line, 1, (size_t)(p - line), f);
+    }
+    return fclose(f) ? ORC_EIO : ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Path-based wrappers (ctypes cannot hand over a FILE*)
+ * ---------------------------------------------------------------------------------------- */
+int orc_fst_text_path(const char *in, uint32_t W, uint32_t S, const char *out_path) {
+    FILE *o = fopen(out_path, "w");
+    if (!o) return ORC_EIO;
+    int rc = orc_fst_text(in, W, S, o);
+    return fclose(o) ? ORC_EIO : rc;
+}
+
+int orc_het_text_path(const char *in, uint32_t W, uint32_t S, const char *out_path) {
+    FILE *o = fopen(out_path, "w");
+    if (!o) return ORC_EIO;
+    int rc = orc_het_text(in, W, S, o);
+    return fclose(o) ? ORC_EIO : rc;
+}
+
+int orc_dxy_text_path(const char *maf1, const char *maf2, const char *sizefile, uint32_t W, uint32_t S,
+                      int minind, int fixedsite, int skip_missing, const char *out_path,
+                      const char *err_path) {
+    FILE *o = fopen(out_path, "w");
+    FILE *e = fopen(err_path, "w");
+    if (!o || !e) { if (o) fclose(o); if (e) fclose(e); return ORC_EIO; }
+    int rc = orc_dxy_text(maf1, maf2, (sizefile && *sizefile) ? sizefile : NULL, W, S, minind,
+                          fixedsite, skip_missing, o, e);
+    int c1 = fclose(o), c2 = fclose(e);
+    return (c1 || c2) ? ORC_EIO : rc;
+}

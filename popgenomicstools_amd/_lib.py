@@ -1,0 +1,104 @@
+"""ctypes binding of include/pgtwin.h (the C-ABI of libpgtwin.so).
+
+This module never computes anything itself: if the shared library is missing it raises, it does
+not fall back to numpy, torch or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpgtwin.so")
+
+PGT_OK, PGT_EARG, PGT_ECAP, PGT_EDEVICE, PGT_EDOMAIN, PGT_ENOMEM = range(6)
+PGT_WIN_COORDS = 1
+PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY = 0, 1, 2
+
+# numpy views of the C structs (layout asserted against ctypes below)
+WIN_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8"), ("label_run", "<u4"), ("flags", "<u4"),
+                      ("start", "<u4"), ("end", "<u4")])
+FST_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("mid", "<u4"), ("n", "<u4"),
+                          ("fst", "<f8"), ("asum", "<f8"), ("bsum", "<f8")])
+HET_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("mid", "<u4"), ("nonmissing", "<u4"),
+                          ("nhet", "<u4"), ("pad_", "<u4"), ("h", "<f8")])
+DXY_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("neff", "<u4"), ("nskip", "<u4"),
+                          ("sum", "<f8")])
+DXY_TOTAL_DTYPE = np.dtype([("sum", "<f8"), ("neff", "<u8"), ("nskip", "<u8")])
+SHARD_DTYPE = np.dtype([("win_begin", "<u8"), ("win_end", "<u8"), ("site_lo", "<u8"), ("site_hi", "<u8")])
+
+assert WIN_DTYPE.itemsize == 32 and FST_ROW_DTYPE.itemsize == 40 and HET_ROW_DTYPE.itemsize == 32
+assert DXY_ROW_DTYPE.itemsize == 24 and DXY_TOTAL_DTYPE.itemsize == 24 and SHARD_DTYPE.itemsize == 32
+
+# every symbol include/pgtwin.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "pgt_open", "pgt_close", "pgt_last_error", "pgt_abi_version",
+    "pgt_build_windows_sites", "pgt_build_windows_bp",
+    "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
+    "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
+    "pgt_fst_reduce_pairs_dev", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
+]
+
+
+class PgtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpgtwin error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libpgtwin.so, building it first if the sources are newer.  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build
+        build.build_lib()
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
+    lib.pgt_open.restype = vp
+    lib.pgt_open.argtypes = [i32]
+    lib.pgt_close.restype = None
+    lib.pgt_close.argtypes = [vp]
+    lib.pgt_last_error.restype = C.c_char_p
+    lib.pgt_last_error.argtypes = [vp]
+    lib.pgt_abi_version.restype = i32
+    lib.pgt_build_windows_sites.argtypes = [vp, sz, u32, u32, vp, sz, C.POINTER(sz)]
+    lib.pgt_build_windows_bp.argtypes = [vp, vp, vp, sz, u32, u32, vp, sz, C.POINTER(sz)]
+    lib.pgt_fst_reduce.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp]
+    lib.pgt_het_reduce.argtypes = [vp, vp, vp, u64, vp, u64, vp]
+    lib.pgt_dxy_reduce.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp]
+    lib.pgt_tree_bytes.restype = sz
+    lib.pgt_tree_bytes.argtypes = [i32, u64]
+    lib.pgt_fst_reduce_dev.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp, vp, sz, vp]
+    lib.pgt_het_reduce_dev.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, sz, vp]
+    lib.pgt_dxy_reduce_dev.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp, vp, sz, vp]
+    lib.pgt_fst_reduce_pairs_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
+    lib.pgt_set_profiling.argtypes = [vp, i32]
+    lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pgt_plan_shards.argtypes = [vp, u64, u32, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("pgt_abi_version",):
+            pass
+    _lib = lib
+    return lib
+
+
+def last_error(ctx=None) -> str:
+    msg = load().pgt_last_error(ctx)
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != PGT_OK:
+        raise PgtError(rc, last_error(ctx))
+
+
+def np_ptr(arr: np.ndarray) -> int:
+    return arr.ctypes.data

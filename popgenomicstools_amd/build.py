@@ -1,0 +1,79 @@
+"""Build libpgtwin.so (HIP kernels + C-ABI) and the retained C++ hosts for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container as well as on the
+GPU box.  Nothing here falls back to a CPU implementation: if the build fails, the package
+cannot be used.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+BIN = os.path.join(PKG, "bin")
+LIB = os.path.join(PKG, "libpgtwin.so")
+
+LIB_SOURCES = ["pgt_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
+HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libpgtwin needs the ROCm toolchain (no CPU fallback exists)")
+    return exe
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {cmd[0]} (exit {r.returncode})")
+
+
+def build_lib(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(ROOT, "include", "pgtwin.h")]
+    if force or _newer(LIB, deps):
+        _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + srcs)
+    return LIB
+
+
+def build_hosts(force: bool = False) -> list[str]:
+    """The retained C++ hosts: same argv and TSV as the reference tools, reduction in libpgtwin."""
+    os.makedirs(BIN, exist_ok=True)
+    out = []
+    common = [os.path.join(HOST, "host_common.h"), os.path.join(ROOT, "include", "pgtwin.h"), LIB]
+    for tool in HOST_TOOLS:
+        src = os.path.join(HOST, tool + "_main.cpp")
+        if not os.path.exists(src):
+            continue
+        exe = os.path.join(BIN, tool)
+        if force or _newer(exe, [src] + common):
+            _run([_hipcc(), "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, src,
+                  "-o", exe, "-L" + PKG, "-lpgtwin", "-Wl,-rpath,$ORIGIN/.."])
+        out.append(exe)
+    return out
+
+
+def build_all(force: bool = False) -> None:
+    build_lib(force)
+    build_hosts(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built", LIB)

@@ -1,0 +1,288 @@
+// pgt_api.cpp — the C-ABI of libpgtwin (include/pgtwin.h): context, argument checks, the
+// host-buffer entry points (copy in -> GPU -> copy out) and the device-resident entry points.
+// There is deliberately no CPU code path here: without a HIP device every reduce fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pgt_internal.h"
+
+struct pgt_ctx {
+    int device = 0;
+    std::string error;
+    bool profiling = false;
+    bool have_timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // build start, build end, query end
+};
+
+namespace {
+
+using namespace pgt;
+
+int ctx_fail(pgt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    set_global_error(msg);
+    return code;
+}
+
+int hip_check(pgt_ctx *ctx, hipError_t e, const char *what) {
+    if (e == hipSuccess) return PGT_OK;
+    return ctx_fail(ctx, PGT_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// RAII device buffer for the host-buffer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(pgt_ctx *ctx, size_t bytes, const char *what) {
+        return hip_check(ctx, hipMalloc(&p, bytes ? bytes : 16), what);
+    }
+    int upload(pgt_ctx *ctx, const void *src, size_t bytes, const char *what) {
+        if (int rc = alloc(ctx, bytes, what)) return rc;
+        if (!bytes) return PGT_OK;
+        return hip_check(ctx, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), what);
+    }
+};
+
+int check_windows_host(pgt_ctx *ctx, const pgt_win *win, uint64_t n_win, uint64_t n, bool need_coords_or_sites) {
+    for (uint64_t i = 0; i < n_win; ++i) {
+        if (win[i].lo > win[i].hi || win[i].hi > n)
+            return ctx_fail(ctx, PGT_EARG, "window range outside [0, n_sites]");
+        if (need_coords_or_sites && win[i].lo == win[i].hi && !(win[i].flags & PGT_WIN_COORDS))
+            return ctx_fail(ctx, PGT_EARG, "empty window without explicit coordinates");
+    }
+    return PGT_OK;
+}
+
+struct EvSet {
+    void *b0 = nullptr, *b1 = nullptr, *q1 = nullptr;
+};
+EvSet events_for(pgt_ctx *ctx) {
+    EvSet e;
+    if (ctx->profiling) {
+        e.b0 = ctx->ev[0];
+        e.b1 = ctx->ev[1];
+        e.q1 = ctx->ev[2];
+        ctx->have_timing = true;
+    }
+    return e;
+}
+
+int use_device(pgt_ctx *ctx) {
+    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+    return hip_check(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgt_abi_version(void) { return PGT_ABI_VERSION; }
+
+pgt_ctx *pgt_open(int device) {
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0) {
+        set_global_error(std::string("pgt_open: no HIP device available (") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                         "); libpgtwin has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n_dev) {
+        set_global_error("pgt_open: device ordinal out of range");
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        set_global_error(std::string("pgt_open: hipGetDeviceProperties: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_global_error(std::string("pgt_open: device is ") + prop.gcnArchName +
+                         ", but libpgtwin carries gfx950 (MI355X) code objects only");
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        set_global_error(std::string("pgt_open: hipSetDevice: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    pgt_ctx *ctx = new pgt_ctx;
+    ctx->device = device;
+    for (auto &ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            set_global_error(std::string("pgt_open: hipEventCreate: ") + hipGetErrorString(e));
+            pgt_close(ctx);
+            return nullptr;
+        }
+    return ctx;
+}
+
+void pgt_close(pgt_ctx *ctx) {
+    if (!ctx) return;
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete ctx;
+}
+
+const char *pgt_last_error(const pgt_ctx *ctx) {
+    if (ctx) return ctx->error.c_str();
+    return global_error().c_str();
+}
+
+size_t pgt_tree_bytes(int stat, uint64_t n_sites) {
+    if (stat < PGT_STAT_FST || stat > PGT_STAT_DXY) return 0;
+    return tree_layout(stat, n_sites).bytes;
+}
+
+int pgt_set_profiling(pgt_ctx *ctx, int enabled) {
+    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+    ctx->profiling = enabled != 0;
+    ctx->have_timing = false;
+    return PGT_OK;
+}
+
+int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms) {
+    if (!ctx || !build_ms || !query_ms) return ctx_fail(ctx, PGT_EARG, "pgt_last_kernel_ms: NULL argument");
+    if (!ctx->have_timing) return ctx_fail(ctx, PGT_EARG, "pgt_last_kernel_ms: no profiled call yet");
+    if (int rc = hip_check(ctx, hipEventSynchronize(ctx->ev[2]), "hipEventSynchronize")) return rc;
+    if (int rc = hip_check(ctx, hipEventElapsedTime(build_ms, ctx->ev[0], ctx->ev[1]), "hipEventElapsedTime")) return rc;
+    return hip_check(ctx, hipEventElapsedTime(query_ms, ctx->ev[1], ctx->ev[2]), "hipEventElapsedTime");
+}
+
+/* ---------------- device-resident entry points ---------------- */
+
+int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *a, const double *const *b,
+                             uint32_t n_pairs, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
+                             void *tree, size_t tree_bytes, void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!a || !b || n_pairs == 0 || !tree || (n_win && (!win || !out || !pos)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    for (uint32_t p = 0; p < n_pairs; ++p)
+        if (!a[p] || !b[p] || !aligned16(a[p]) || !aligned16(b[p]))
+            return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: f64 columns must be non-NULL and 16-byte aligned");
+    if (!aligned16(tree) || tree_bytes < (size_t)n_pairs * pgt_tree_bytes(PGT_STAT_FST, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error);
+}
+
+int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
+                       const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, size_t tree_bytes,
+                       void *stream) {
+    const double *pa[1] = {a}, *pb[1] = {b};
+    return pgt_fst_reduce_pairs_dev(ctx, pos, pa, pb, 1, n, win, n_win, out, tree, tree_bytes, stream);
+}
+
+int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
+                       uint64_t n_win, pgt_het_row *out, void *tree, size_t tree_bytes, void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!g || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    if (!aligned16(g)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: genotype column must be 16-byte aligned");
+    if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: at most 2^32-1 sites per call");
+    if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_HET, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error);
+}
+
+int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+                       const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+                       pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, size_t tree_bytes, void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!p1 || !p2 || !n1 || !n2 || !tree || (n_win && (!win || !out)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
+    if (!aligned16(p1) || !aligned16(p2) || (reinterpret_cast<uintptr_t>(n1) & 7u) || (reinterpret_cast<uintptr_t>(n2) & 7u))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: f64 columns need 16-byte, i32 columns 8-byte alignment");
+    if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: at most 2^32-1 sites per call");
+    if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_dxy(pos, p1, p2, n1, n2, n, minind, win, n_win, out, tot, tree, stream, e.b0, e.b1, e.q1,
+                      &ctx->error);
+}
+
+/* ---------------- host-buffer entry points ---------------- */
+
+int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
+                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
+    if (int rc = use_device(ctx)) return rc;
+    if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    DevBuf dpos, da, db, dwin, dout, dtree;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
+    if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
+    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_fst_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(da.p),
+                                    static_cast<double *>(db.p), n, static_cast<pgt_win *>(dwin.p), n_win,
+                                    static_cast<pgt_fst_row *>(dout.p), dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
+    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
+    return PGT_OK;
+}
+
+int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
+                   uint64_t n_win, pgt_het_row *out) {
+    if (int rc = use_device(ctx)) return rc;
+    if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    DevBuf dpos, dg, dwin, dout, dtree;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
+    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_het_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n,
+                                    static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_het_row *>(dout.p),
+                                    dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
+    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
+    return PGT_OK;
+}
+
+int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+                   const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+                   pgt_dxy_row *out, pgt_dxy_total *tot) {
+    if (int rc = use_device(ctx)) return rc;
+    if ((n && (!pos || !p1 || !p2 || !n1 || !n2)) || (n_win && (!win || !out)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    DevBuf dpos, d1, d2, dn1, dn2, dwin, dout, dtot, dtree;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;
+    if (int rc = d2.upload(ctx, p2, n * sizeof(double), "upload p2")) return rc;
+    if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
+    if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
+    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
+    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
+    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_dxy_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p),
+                                    static_cast<double *>(d2.p), static_cast<int32_t *>(dn1.p),
+                                    static_cast<int32_t *>(dn2.p), n, minind, static_cast<pgt_win *>(dwin.p), n_win,
+                                    static_cast<pgt_dxy_row *>(dout.p), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr,
+                                    dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
+    if (n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
+    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
+    return PGT_OK;
+}
+
+}  // extern "C"

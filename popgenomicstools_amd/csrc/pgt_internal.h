@@ -1,0 +1,79 @@
+// pgt_internal.h — shared between the HIP kernels, the C-ABI and the host window builders.
+// Not part of the public interface (that is include/pgtwin.h).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "pgtwin.h"
+
+namespace pgt {
+
+constexpr int kWave = 64;        // gfx950 wavefront
+constexpr int kRadix = 64;       // children per tree node above the leaf level = one lane each
+constexpr int kLeafF64 = 128;    // sites per level-1 node for f64 columns: one 16-B load per lane
+constexpr int kLeafI8 = 1024;    // sites per level-1 node for the int8 genotype column: 16 B per lane
+constexpr int kMaxLevels = 8;
+
+// Node sizes in bytes (all levels of one tree use the same node type).
+constexpr size_t kNodeFst = 16;  // {double Σa, double Σb}
+constexpr size_t kNodeHet = 8;   // {u32 nonmissing, u32 nhet}
+constexpr size_t kNodeDxy = 16;  // {double Σd, u32 neff, u32 nskip}
+
+struct TreeLayout {
+    int n_levels = 0;                   // levels 1..n_levels exist
+    uint64_t count[kMaxLevels] = {};    // nodes stored per level (level 1 padded to 64 * count[1])
+    size_t offset[kMaxLevels] = {};     // byte offset of each level in the workspace
+    size_t bytes = 0;
+};
+
+inline int leaf_sites(int stat) { return stat == PGT_STAT_HET ? kLeafI8 : kLeafF64; }
+inline size_t node_bytes(int stat) { return stat == PGT_STAT_HET ? kNodeHet : 16; }
+
+// Level 1 and 2 come out of the streaming build kernel; higher levels are added while a level
+// still has more than 64 nodes (so the top level is always reducible by one wave-wide load).
+inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
+    TreeLayout t;
+    const uint64_t leaf = (uint64_t)leaf_sites(stat);
+    const size_t nb = node_bytes(stat);
+    uint64_t n_l2 = (n_sites + leaf * kRadix - 1) / (leaf * kRadix);
+    if (n_l2 == 0) n_l2 = 1;
+    uint64_t c = n_l2 * kRadix;
+    size_t off = 0;
+    int k = 0;
+    auto push = [&](uint64_t cnt) {
+        t.count[k] = cnt;
+        t.offset[k] = off;
+        off += ((cnt * nb + 255) / 256) * 256;
+        ++k;
+    };
+    push(c);       // level 1
+    push(n_l2);    // level 2
+    c = n_l2;
+    while (c > (uint64_t)kRadix && k < kMaxLevels) {
+        c = (c + kRadix - 1) / kRadix;
+        push(c);
+    }
+    t.n_levels = k;
+    t.bytes = off;
+    return t;
+}
+
+// ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------
+int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
+               uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
+               void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err);
+int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
+               pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
+               void *ev_query1, std::string *err);
+int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+               const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+               pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, void *stream, void *ev_build0,
+               void *ev_build1, void *ev_query1, std::string *err);
+
+// thread-local message for the ctx-less entry points
+void set_global_error(const std::string &msg);
+const std::string &global_error();
+
+}  // namespace pgt

@@ -1,0 +1,586 @@
+// pgt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the window-scan engine.
+//
+// What is replaced: the per-window re-summation of the reference's calcWindow
+//   fstWindow.cpp:76-85 (Σa, Σb, ratio)   hetWindow.cpp:73-84 (counts, ratio)
+//   dxyWindow.cpp:174-186 (Σd, neffective, nskip)   dxyWindow.cpp:381-385 (per-site dxy, totals)
+// and the O(W) buffer shift after every window (fstWindow.cpp:92-99).
+//
+// How: every window of every tool/mode is one contiguous range [lo,hi) of the global site index
+// (SURVEY.md §4), so the device keeps a radix-64 RANGE TREE over the site axis:
+//   level 0 = the site columns themselves (SoA in HBM),
+//   level 1 = one node per `leaf` sites  (128 for f64 columns, 1024 for the int8 column:
+//             exactly one 16-byte load per lane of a 64-lane wave),
+//   level k = one node per 64 level-(k-1) nodes (one lane per child).
+// BUILD is the only pass that streams the columns: one wave owns one level-2 tile (64 leaf
+// tiles), issues 16-byte loads only, reduces each leaf tile with a wave butterfly, parks the
+// leaf total in lane j, and at the end stores the 64 level-1 nodes with ONE coalesced 1-KiB
+// wave store plus one level-2 node.  No LDS, no barrier, no atomics: bitwise deterministic.
+// QUERY gives one wave per window: at each level the ragged left/right remainders (< radix
+// nodes each) are read lane-parallel, the aligned interior moves up a level.
+// Memory-bound: 2 f64 adds per 16 B, no contraction to feed MFMA (none is used).
+#include <hip/hip_runtime.h>
+
+#include "pgt_internal.h"
+
+namespace pgt {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// wave64 cross-lane sums.  Steps 1-4 stay inside a 16-lane DPP row (quad_perm, then the two
+// mirror controls, valid because after each step the value is uniform inside the sub-group);
+// steps 5-6 cross rows through ds_bpermute.  Every lane returns the same bits.
+// ------------------------------------------------------------------------------------------
+constexpr int kDppQuadXor1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<kDppQuadXor1>(v);
+    v += dpp_f64<kDppQuadXor2>(v);
+    v += dpp_f64<kDppRowHalfMirror>(v);
+    v += dpp_f64<kDppRowMirror>(v);
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += dpp_u32<kDppQuadXor1>(v);
+    v += dpp_u32<kDppQuadXor2>(v);
+    v += dpp_u32<kDppRowHalfMirror>(v);
+    v += dpp_u32<kDppRowMirror>(v);
+    v += (uint32_t)__shfl_xor((int)v, 16, kWave);
+    v += (uint32_t)__shfl_xor((int)v, 32, kWave);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tree nodes
+// ------------------------------------------------------------------------------------------
+struct alignas(16) NodeFst { double x, y; };
+struct alignas(8) NodeHet { uint32_t nonmiss, nhet; };
+struct alignas(16) NodeDxy { double s; uint32_t neff, nskip; };
+
+__device__ __forceinline__ void node_add(NodeFst &a, const NodeFst &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void node_add(NodeHet &a, const NodeHet &b) { a.nonmiss += b.nonmiss; a.nhet += b.nhet; }
+__device__ __forceinline__ void node_add(NodeDxy &a, const NodeDxy &b) { a.s += b.s; a.neff += b.neff; a.nskip += b.nskip; }
+__device__ __forceinline__ NodeFst node_wave_sum(NodeFst v) { return {wave_sum(v.x), wave_sum(v.y)}; }
+__device__ __forceinline__ NodeHet node_wave_sum(NodeHet v) { return {wave_sum(v.nonmiss), wave_sum(v.nhet)}; }
+__device__ __forceinline__ NodeDxy node_wave_sum(NodeDxy v) { return {wave_sum(v.s), wave_sum(v.neff), wave_sum(v.nskip)}; }
+
+constexpr int kMaxPairs = 32;
+struct PairCols {
+    const double *a[kMaxPairs];
+    const double *b[kMaxPairs];
+};
+
+struct TreeView {
+    char *base;            // workspace of pair 0
+    size_t pair_stride;    // bytes between the trees of consecutive pairs
+    size_t off[kMaxLevels];
+    int n_levels;
+};
+
+// ------------------------------------------------------------------------------------------
+// BUILD, fst: level-1 {Σa,Σb} per 128 sites, level-2 per 8192 sites.        16 B/site read.
+// grid.x: waves stride over level-2 tiles; grid.y: population pair.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2,
+                                                        TreeView tv) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const double *__restrict__ a = cols.a[blockIdx.y];
+    const double *__restrict__ b = cols.b[blockIdx.y];
+    char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
+    NodeFst *__restrict__ l1 = reinterpret_cast<NodeFst *>(tree + tv.off[0]);
+    NodeFst *__restrict__ l2 = reinterpret_cast<NodeFst *>(tree + tv.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;  // 8192 sites
+
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        double keep_a = 0.0, keep_b = 0.0;
+        if (base + kTile2 <= n) {
+            const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(a + base);
+            const double2 *__restrict__ pb = reinterpret_cast<const double2 *>(b + base);
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += 4) {
+                double2 va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // 8 x 16-byte loads in flight per lane
+                    va[u] = pa[(j + u) * kWave + lane];
+                    vb[u] = pb[(j + u) * kWave + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double sa = wave_sum(va[u].x + va[u].y);
+                    const double sb = wave_sum(vb[u].x + vb[u].y);
+                    if (lane == j + u) { keep_a = sa; keep_b = sb; }
+                }
+            }
+        } else {  // last, partial level-2 tile: guarded 8-byte loads, zero fill
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
+                if (base + (uint64_t)j * kLeafF64 >= n) break;  // wave-uniform
+                const double a0 = i0 < n ? a[i0] : 0.0, a1 = i0 + 1 < n ? a[i0 + 1] : 0.0;
+                const double b0 = i0 < n ? b[i0] : 0.0, b1 = i0 + 1 < n ? b[i0 + 1] : 0.0;
+                const double sa = wave_sum(a0 + a1);
+                const double sb = wave_sum(b0 + b1);
+                if (lane == j) { keep_a = sa; keep_b = sb; }
+            }
+        }
+        l1[t * kRadix + lane] = NodeFst{keep_a, keep_b};  // one 1-KiB coalesced wave store
+        const double ta = wave_sum(keep_a), tb = wave_sum(keep_b);
+        if (lane == 0) l2[t] = NodeFst{ta, tb};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BUILD, het: level-1 {nonmissing, nhet} per 1024 sites (16 int8 genotypes per lane).  1 B/site.
+// nonmissing = g >= 0, nhet = g == 1 (hetWindow.cpp:78-80), counted bytewise on packed words.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void het_count_word(uint32_t w, uint32_t &nonmiss, uint32_t &nhet) {
+    nonmiss += 4u - (uint32_t)__popc(w & 0x80808080u);
+    const uint32_t x = w ^ 0x01010101u;  // bytes equal to 1 become 0
+    const uint32_t y = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 per zero byte
+    nhet += (uint32_t)__popc(y);
+}
+
+__global__ __launch_bounds__(256) void het_build_kernel(const int8_t *__restrict__ g, uint64_t n,
+                                                        uint64_t n_l2, TreeView tv) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    NodeHet *__restrict__ l1 = reinterpret_cast<NodeHet *>(tv.base + tv.off[0]);
+    NodeHet *__restrict__ l2 = reinterpret_cast<NodeHet *>(tv.base + tv.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafI8 * kRadix;  // 65536 sites
+
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        uint32_t keep_nm = 0, keep_nh = 0;
+        if (base + kTile2 <= n) {
+            const uint4 *__restrict__ pg = reinterpret_cast<const uint4 *>(g + base);
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += 8) {
+                uint4 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = pg[(j + u) * kWave + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    uint32_t nm = 0, nh = 0;
+                    het_count_word(w[u].x, nm, nh);
+                    het_count_word(w[u].y, nm, nh);
+                    het_count_word(w[u].z, nm, nh);
+                    het_count_word(w[u].w, nm, nh);
+                    nm = wave_sum(nm);
+                    nh = wave_sum(nh);
+                    if (lane == j + u) { keep_nm = nm; keep_nh = nh; }
+                }
+            }
+        } else {
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t tile0 = base + (uint64_t)j * kLeafI8;
+                if (tile0 >= n) break;  // wave-uniform
+                uint32_t nm = 0, nh = 0;
+                for (int q = 0; q < 16; ++q) {
+                    const uint64_t i = tile0 + (uint64_t)lane * 16 + q;
+                    if (i < n) {
+                        const int v = g[i];
+                        nm += v >= 0;
+                        nh += v == 1;
+                    }
+                }
+                nm = wave_sum(nm);
+                nh = wave_sum(nh);
+                if (lane == j) { keep_nm = nm; keep_nh = nh; }
+            }
+        }
+        l1[t * kRadix + lane] = NodeHet{keep_nm, keep_nh};
+        const uint32_t tm = wave_sum(keep_nm), th = wave_sum(keep_nh);
+        if (lane == 0) l2[t] = NodeHet{tm, th};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BUILD, dxy: per-site value exactly as dxyWindow.cpp:381 (no FMA contraction: the products
+// and sums are rounded one by one, as the host's SSE2 code does), then level-1 {Σd over d>=0,
+// neffective, nskip} per 128 sites.                                            24 B/site read.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dxy_site(double p1, double p2, int n1, int n2, int minind) {
+    const double d = __dadd_rn(__dmul_rn(p1, __dsub_rn(1.0, p2)), __dmul_rn(p2, __dsub_rn(1.0, p1)));
+    return (n1 >= minind && n2 >= minind) ? d : -9.0;
+}
+__device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.cpp:180-185
+    if (v >= 0.0) { acc.s += v; acc.neff += 1; }
+    else if (v == -9.0) acc.nskip += 1;
+}
+
+__global__ __launch_bounds__(256) void dxy_build_kernel(const double *__restrict__ p1,
+                                                        const double *__restrict__ p2,
+                                                        const int32_t *__restrict__ n1,
+                                                        const int32_t *__restrict__ n2, uint64_t n,
+                                                        int minind, uint64_t n_l2, TreeView tv) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    NodeDxy *__restrict__ l1 = reinterpret_cast<NodeDxy *>(tv.base + tv.off[0]);
+    NodeDxy *__restrict__ l2 = reinterpret_cast<NodeDxy *>(tv.base + tv.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        NodeDxy keep{0.0, 0u, 0u};
+        if (base + kTile2 <= n) {
+            const double2 *__restrict__ q1 = reinterpret_cast<const double2 *>(p1 + base);
+            const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(p2 + base);
+            const int2 *__restrict__ m1 = reinterpret_cast<const int2 *>(n1 + base);
+            const int2 *__restrict__ m2 = reinterpret_cast<const int2 *>(n2 + base);
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += 2) {
+                double2 x1[2], x2[2];
+                int2 k1[2], k2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    x1[u] = q1[(j + u) * kWave + lane];
+                    x2[u] = q2[(j + u) * kWave + lane];
+                    k1[u] = m1[(j + u) * kWave + lane];
+                    k2[u] = m2[(j + u) * kWave + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    NodeDxy acc{0.0, 0u, 0u};
+                    dxy_acc(acc, dxy_site(x1[u].x, x2[u].x, k1[u].x, k2[u].x, minind));
+                    dxy_acc(acc, dxy_site(x1[u].y, x2[u].y, k1[u].y, k2[u].y, minind));
+                    acc = node_wave_sum(acc);
+                    if (lane == j + u) keep = acc;
+                }
+            }
+        } else {
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t tile0 = base + (uint64_t)j * kLeafF64;
+                if (tile0 >= n) break;  // wave-uniform
+                NodeDxy acc{0.0, 0u, 0u};
+                for (int q = 0; q < 2; ++q) {
+                    const uint64_t i = tile0 + 2 * lane + q;
+                    if (i < n) dxy_acc(acc, dxy_site(p1[i], p2[i], n1[i], n2[i], minind));
+                }
+                acc = node_wave_sum(acc);
+                if (lane == j) keep = acc;
+            }
+        }
+        l1[t * kRadix + lane] = keep;
+        const NodeDxy tot = node_wave_sum(keep);
+        if (lane == 0) l2[t] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Upper levels (only exist when level 2 has more than 64 nodes): parent = Σ of 64 children.
+// ------------------------------------------------------------------------------------------
+template <class Node>
+__global__ __launch_bounds__(256) void tree_up_kernel(TreeView tv, int child_level /*0-based slot*/,
+                                                      uint64_t n_child, uint64_t n_parent) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
+    const Node *__restrict__ child = reinterpret_cast<const Node *>(tree + tv.off[child_level]);
+    Node *__restrict__ parent = reinterpret_cast<Node *>(tree + tv.off[child_level + 1]);
+    for (uint64_t p = wave0; p < n_parent; p += n_waves) {
+        const uint64_t i = p * kRadix + lane;
+        Node v{};
+        if (i < n_child) v = child[i];
+        v = node_wave_sum(v);
+        if (lane == 0) parent[p] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// QUERY: one wave per window.
+// ------------------------------------------------------------------------------------------
+struct FstTraits {
+    using Node = NodeFst;
+    using Row = pgt_fst_row;
+    static constexpr int kLeaf = kLeafF64;
+    struct Args { PairCols cols; };
+    struct Cols { const double *a, *b; };
+    static __device__ __forceinline__ Cols cols(const Args &g, int pair) { return {g.cols.a[pair], g.cols.b[pair]}; }
+    static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) { return {c.a[i], c.b[i]}; }
+    static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
+                                                  uint64_t lo, uint64_t hi) {
+        Row r;
+        r.start = start;
+        r.end = end;
+        r.mid = (uint32_t)(start + end) / 2u;  // unsigned 32-bit wrap, fstWindow.cpp:73
+        r.n = (uint32_t)(hi - lo);
+        // the reference starts its sums at +0.0 (fstWindow.cpp:76-77): a window of only -0.0
+        // must give +0.0, which adding +0.0 restores without touching any other value
+        r.asum = t.x + 0.0;
+        r.bsum = t.y + 0.0;
+        r.fst = r.bsum != 0.0 ? r.asum / r.bsum : 0.0;  // fstWindow.cpp:85
+        *out = r;
+    }
+    static __device__ __forceinline__ void store_total(pgt_dxy_total *, const Node &) {}
+};
+
+struct HetTraits {
+    using Node = NodeHet;
+    using Row = pgt_het_row;
+    static constexpr int kLeaf = kLeafI8;
+    struct Args { const int8_t *g; };
+    using Cols = const int8_t *;
+    static __device__ __forceinline__ Cols cols(const Args &g, int) { return g.g; }
+    static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) {
+        const int v = c[i];
+        return {(uint32_t)(v >= 0), (uint32_t)(v == 1)};
+    }
+    static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
+                                                  uint64_t, uint64_t) {
+        Row r;
+        r.start = start;
+        r.end = end;
+        r.mid = (uint32_t)(start + end) / 2u;  // hetWindow.cpp:70
+        r.nonmissing = t.nonmiss;
+        r.nhet = t.nhet;
+        r.pad_ = 0;
+        r.h = t.nonmiss != 0 ? (double)t.nhet / (double)t.nonmiss : 0.0;  // hetWindow.cpp:84
+        *out = r;
+    }
+    static __device__ __forceinline__ void store_total(pgt_dxy_total *, const Node &) {}
+};
+
+struct DxyTraits {
+    using Node = NodeDxy;
+    using Row = pgt_dxy_row;
+    static constexpr int kLeaf = kLeafF64;
+    struct Args { const double *p1, *p2; const int32_t *n1, *n2; int minind; };
+    using Cols = Args;
+    static __device__ __forceinline__ Cols cols(const Args &g, int) { return g; }
+    static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) {
+        Node v{0.0, 0u, 0u};
+        dxy_acc(v, dxy_site(c.p1[i], c.p2[i], c.n1[i], c.n2[i], c.minind));
+        return v;
+    }
+    static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
+                                                  uint64_t, uint64_t) {
+        Row r;
+        r.start = start;
+        r.end = end;
+        r.neff = t.neff;
+        r.nskip = t.nskip;
+        r.sum = t.s + 0.0;
+        *out = r;
+    }
+    // genome-wide line, dxyWindow.cpp:382-385,429-433 (equal to Σ over d != -9 for freq in [0,1])
+    static __device__ __forceinline__ void store_total(pgt_dxy_total *tot, const Node &t) {
+        tot->sum = t.s + 0.0;
+        tot->neff = t.neff;
+        tot->nskip = t.nskip;
+    }
+};
+
+template <class Tr>
+__device__ __forceinline__ void sum_level(typename Tr::Node &acc, const typename Tr::Cols &c,
+                                          const char *tree, const TreeView &tv, int level,
+                                          uint64_t from, uint64_t to, int lane) {
+    if (level == 0) {
+        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, Tr::leaf(c, i));
+    } else {
+        const typename Tr::Node *nodes = reinterpret_cast<const typename Tr::Node *>(tree + tv.off[level - 1]);
+        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, nodes[i]);
+    }
+}
+
+template <class Tr>
+__global__ __launch_bounds__(256) void query_kernel(typename Tr::Args args, const uint32_t *__restrict__ pos,
+                                                    TreeView tv, const pgt_win *__restrict__ win,
+                                                    uint64_t n_win, typename Tr::Row *__restrict__ out,
+                                                    uint64_t n_sites, pgt_dxy_total *tot) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int pair = blockIdx.y;
+    const typename Tr::Cols c = Tr::cols(args, pair);
+    const char *tree = tv.base + (size_t)pair * tv.pair_stride;
+    const uint64_t n_items = n_win + (tot ? 1 : 0);  // the extra item is the genome-wide total
+
+    for (uint64_t w = wave0; w < n_items; w += n_waves) {
+        const bool is_total = w == n_win;
+        pgt_win wd;
+        if (is_total) {
+            wd.lo = 0; wd.hi = n_sites; wd.flags = PGT_WIN_COORDS; wd.start = wd.end = 0; wd.label_run = 0;
+        } else {
+            wd = win[w];
+        }
+        // clamp to the columns so that a corrupt table can never fault the GPU
+        const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
+        const uint64_t lo = wd.lo < hi ? wd.lo : hi;
+        typename Tr::Node acc{};
+        uint64_t clo = lo, chi = hi;  // current range, in nodes of level k (level 0 = sites)
+        for (int k = 0;; ++k) {
+            if (k == tv.n_levels) {  // top level: whatever is left
+                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane);
+                break;
+            }
+            const uint64_t r = k == 0 ? (uint64_t)Tr::kLeaf : (uint64_t)kRadix;
+            const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
+            if (ulo >= uhi) {  // no whole parent inside: finish at this level
+                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane);
+                break;
+            }
+            sum_level<Tr>(acc, c, tree, tv, k, clo, ulo * r, lane);  // ragged left  (< r nodes)
+            sum_level<Tr>(acc, c, tree, tv, k, uhi * r, chi, lane);  // ragged right (< r nodes)
+            clo = ulo;
+            chi = uhi;
+        }
+        acc = node_wave_sum(acc);
+        if (lane == 0) {
+            if (is_total) {
+                Tr::store_total(tot, acc);
+            } else {
+                uint32_t start = wd.start, end = wd.end;
+                if (!(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
+                    start = hi > lo ? pos[lo] : 0u;
+                    end = hi > lo ? pos[hi - 1] : 0u;
+                }
+                Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi);
+            }
+        }
+    }
+}
+
+inline int hip_fail(hipError_t e, const char *what, std::string *err) {
+    if (e == hipSuccess) return PGT_OK;
+    if (err) *err = std::string(what) + ": " + hipGetErrorString(e);
+    return PGT_EDEVICE;
+}
+
+inline unsigned build_grid(uint64_t n_l2) {
+    // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; cap at 8 resident
+    // workgroups per CU x 256 CUs and grid-stride the rest.
+    uint64_t blocks = (n_l2 + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+inline unsigned query_grid(uint64_t n_items) {
+    uint64_t blocks = (n_items + 3) / 4;
+    if (blocks > (1u << 16)) blocks = 1u << 16;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride) {
+    TreeView tv{};
+    tv.base = static_cast<char *>(tree);
+    tv.pair_stride = pair_stride;
+    tv.n_levels = tl.n_levels;
+    for (int k = 0; k < tl.n_levels; ++k) tv.off[k] = tl.offset[k];
+    return tv;
+}
+
+template <class Node>
+int launch_upper(const TreeLayout &tl, const TreeView &tv, unsigned n_pairs, hipStream_t s, std::string *err) {
+    for (int k = 2; k < tl.n_levels; ++k) {  // slot k-1 -> slot k
+        const uint64_t n_child = tl.count[k - 1], n_parent = tl.count[k];
+        dim3 grid(query_grid(n_parent), n_pairs);
+        hipLaunchKernelGGL(tree_up_kernel<Node>, grid, dim3(256), 0, s, tv, k - 1, n_child, n_parent);
+        if (int rc = hip_fail(hipGetLastError(), "tree_up_kernel", err)) return rc;
+    }
+    return PGT_OK;
+}
+
+inline int record(void *ev, hipStream_t s, std::string *err) {
+    if (!ev) return PGT_OK;
+    return hip_fail(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord", err);
+}
+
+}  // namespace
+
+int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
+               uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
+               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
+    for (uint32_t p0 = 0; p0 < n_pairs; p0 += kMaxPairs) {
+        const uint32_t np = n_pairs - p0 < (uint32_t)kMaxPairs ? n_pairs - p0 : (uint32_t)kMaxPairs;
+        PairCols cols{};
+        for (uint32_t p = 0; p < np; ++p) { cols.a[p] = a[p0 + p]; cols.b[p] = b[p0 + p]; }
+        const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes);
+        if (p0 == 0) if (int rc = record(ev_build0, s, err)) return rc;
+        if (n > 0) {
+            hipLaunchKernelGGL(fst_build_kernel, dim3(build_grid(tl.count[1]), np), dim3(256), 0, s, cols, n,
+                               tl.count[1], tv);
+            if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
+            if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
+        }
+        if (p0 + np >= n_pairs) if (int rc = record(ev_build1, s, err)) return rc;
+        if (n_win > 0) {
+            FstTraits::Args args{cols};
+            hipLaunchKernelGGL(query_kernel<FstTraits>, dim3(query_grid(n_win), np), dim3(256), 0, s, args, pos,
+                               tv, win, n_win, out + (uint64_t)p0 * n_win, n, (pgt_dxy_total *)nullptr);
+            if (int rc = hip_fail(hipGetLastError(), "query_kernel<fst>", err)) return rc;
+        }
+    }
+    return record(ev_query1, s, err);
+}
+
+int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
+               pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1,
+               std::string *err) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout tl = tree_layout(PGT_STAT_HET, n);
+    const TreeView tv = make_view(tl, tree, tl.bytes);
+    if (int rc = record(ev_build0, s, err)) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s, g, n, tl.count[1], tv);
+        if (int rc = hip_fail(hipGetLastError(), "het_build_kernel", err)) return rc;
+        if (int rc = launch_upper<NodeHet>(tl, tv, 1, s, err)) return rc;
+    }
+    if (int rc = record(ev_build1, s, err)) return rc;
+    if (n_win > 0) {
+        HetTraits::Args args{g};
+        hipLaunchKernelGGL(query_kernel<HetTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win,
+                           n_win, out, n, (pgt_dxy_total *)nullptr);
+        if (int rc = hip_fail(hipGetLastError(), "query_kernel<het>", err)) return rc;
+    }
+    return record(ev_query1, s, err);
+}
+
+int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
+               uint64_t n, int minind, const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
+               void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout tl = tree_layout(PGT_STAT_DXY, n);
+    const TreeView tv = make_view(tl, tree, tl.bytes);
+    if (int rc = record(ev_build0, s, err)) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s, p1, p2, n1, n2, n,
+                           minind, tl.count[1], tv);
+        if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
+        if (int rc = launch_upper<NodeDxy>(tl, tv, 1, s, err)) return rc;
+    }
+    if (int rc = record(ev_build1, s, err)) return rc;
+    if (n_win > 0 || tot) {
+        DxyTraits::Args args{p1, p2, n1, n2, minind};
+        hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
+                           win, n_win, out, n, tot);
+        if (int rc = hip_fail(hipGetLastError(), "query_kernel<dxy>", err)) return rc;
+    }
+    return record(ev_query1, s, err);
+}
+
+}  // namespace pgt

@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's three window tools over in-memory columns.
+
+Reference interface mirrored (file:line in the reference tree):
+  fstWindow  <file> [W] [S]            fstWindow.cpp:37-67,109-155   -> fst_window(chr, pos, a, b, W, S)
+  hetWindow  <file> [W] [S]            hetWindow.cpp:34-64,107-153   -> het_window(chr, pos, g, W, S)
+  dxyWindow  -winsize -stepsize -minind -fixedsite -sizefile -skip_missing <maf1> <maf2>
+                                       dxyWindow.cpp:63-139,253-436  -> dxy_window(...)
+Argument meaning, defaults (W=S=1 for fst/het; W=S=0, minind=1, fixedsite=0, skip_missing=0 for
+dxy) and error behaviour (an exception where the tool exits 255) follow those lines.
+
+All arithmetic happens in libpgtwin.so on the GPU.  This file only shapes buffers: numpy for
+host columns, torch tensors for device-resident columns (torch is plumbing here: allocation,
+streams, torch.distributed; it never computes a statistic).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_STAT_DXY,
+                   PGT_STAT_FST, PGT_STAT_HET, SHARD_DTYPE, WIN_DTYPE, PgtError, check)
+
+
+# ---------------------------------------------------------------------------------------------
+# window tables (host, no GPU)
+# ---------------------------------------------------------------------------------------------
+def run_lengths(chr_ids) -> np.ndarray:
+    """Lengths of the runs of equal adjacent chromosome ids (the reference compares adjacent
+    names only, fstWindow.cpp:132)."""
+    c = np.asarray(chr_ids)
+    if c.size == 0:
+        return np.zeros(0, dtype=np.uint64)
+    cuts = np.flatnonzero(c[1:] != c[:-1]) + 1
+    edges = np.concatenate(([0], cuts, [c.size]))
+    return np.diff(edges).astype(np.uint64)
+
+
+def build_windows_sites(run_len, W: int, S: int) -> np.ndarray:
+    lib = _lib.load()
+    rl = np.ascontiguousarray(run_len, dtype=np.uint64)
+    n_out = C.c_size_t(0)
+    check(lib.pgt_build_windows_sites(rl.ctypes.data, rl.size, W, S, None, 0, C.byref(n_out)))
+    out = np.zeros(n_out.value, dtype=WIN_DTYPE)
+    check(lib.pgt_build_windows_sites(rl.ctypes.data, rl.size, W, S, out.ctypes.data, out.size, C.byref(n_out)))
+    return out
+
+
+def build_windows_bp(pos, run_len, chr_len, W: int, S: int) -> np.ndarray:
+    lib = _lib.load()
+    p = np.ascontiguousarray(pos, dtype=np.uint32)
+    rl = np.ascontiguousarray(run_len, dtype=np.uint64)
+    cl = np.ascontiguousarray(chr_len, dtype=np.uint32)
+    if cl.size != rl.size or int(rl.sum()) != p.size:
+        raise PgtError(_lib.PGT_EARG, "build_windows_bp: run_len / chr_len / pos sizes disagree")
+    n_out = C.c_size_t(0)
+    check(lib.pgt_build_windows_bp(p.ctypes.data, rl.ctypes.data, cl.ctypes.data, rl.size, W, S, None, 0, C.byref(n_out)))
+    out = np.zeros(n_out.value, dtype=WIN_DTYPE)
+    check(lib.pgt_build_windows_bp(p.ctypes.data, rl.ctypes.data, cl.ctypes.data, rl.size, W, S,
+                                   out.ctypes.data, out.size, C.byref(n_out)))
+    return out
+
+
+def plan_shards(win: np.ndarray, n_ranks: int) -> np.ndarray:
+    lib = _lib.load()
+    w = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+    out = np.zeros(n_ranks, dtype=SHARD_DTYPE)
+    check(lib.pgt_plan_shards(w.ctypes.data if w.size else None, w.size, n_ranks, out.ctypes.data))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# context
+# ---------------------------------------------------------------------------------------------
+class Context:
+    """One GPU, one thread (include/pgtwin.h conventions).  Raises PgtError if no gfx950 device
+    is usable: there is no CPU path."""
+
+    def __init__(self, device: int = -1):
+        self._lib = _lib.load()
+        self._ctx = self._lib.pgt_open(device)
+        if not self._ctx:
+            raise PgtError(_lib.PGT_EDEVICE, _lib.last_error(None))
+
+    def close(self):
+        if self._ctx:
+            self._lib.pgt_close(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        check(rc, self._ctx)
+
+    # ---- host buffers ------------------------------------------------------------------
+    def fst_reduce(self, pos, a, b, win) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        win = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+        if not (pos.size == a.size == b.size):
+            raise PgtError(_lib.PGT_EARG, "fst_reduce: column lengths differ")
+        out = np.zeros(win.size, dtype=FST_ROW_DTYPE)
+        self._check(self._lib.pgt_fst_reduce(self._ctx, pos.ctypes.data, a.ctypes.data, b.ctypes.data, pos.size,
+                                             win.ctypes.data, win.size, out.ctypes.data))
+        return out
+
+    def het_reduce(self, pos, g, win) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        g = np.ascontiguousarray(g, dtype=np.int8)
+        win = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+        if pos.size != g.size:
+            raise PgtError(_lib.PGT_EARG, "het_reduce: column lengths differ")
+        out = np.zeros(win.size, dtype=HET_ROW_DTYPE)
+        self._check(self._lib.pgt_het_reduce(self._ctx, pos.ctypes.data, g.ctypes.data, pos.size,
+                                             win.ctypes.data, win.size, out.ctypes.data))
+        return out
+
+    def dxy_reduce(self, pos, p1, p2, n1, n2, minind, win):
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        p1 = np.ascontiguousarray(p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(p2, dtype=np.float64)
+        n1 = np.ascontiguousarray(n1, dtype=np.int32)
+        n2 = np.ascontiguousarray(n2, dtype=np.int32)
+        win = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+        if not (pos.size == p1.size == p2.size == n1.size == n2.size):
+            raise PgtError(_lib.PGT_EARG, "dxy_reduce: column lengths differ")
+        out = np.zeros(win.size, dtype=DXY_ROW_DTYPE)
+        tot = np.zeros(1, dtype=DXY_TOTAL_DTYPE)
+        self._check(self._lib.pgt_dxy_reduce(self._ctx, pos.ctypes.data, p1.ctypes.data, p2.ctypes.data,
+                                             n1.ctypes.data, n2.ctypes.data, pos.size, int(minind),
+                                             win.ctypes.data, win.size, out.ctypes.data, tot.ctypes.data))
+        return out, tot[0]
+
+    # ---- device-resident columns (torch CUDA tensors) -------------------------------------
+    @staticmethod
+    def _stream(stream):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(s.cuda_stream)
+
+    @staticmethod
+    def tree_bytes(stat: int, n_sites: int) -> int:
+        return int(_lib.load().pgt_tree_bytes(stat, n_sites))
+
+    @staticmethod
+    def _dev(t, dtype, name):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+            raise PgtError(_lib.PGT_EARG, f"{name}: expected a contiguous CUDA tensor of {dtype}")
+        return t.data_ptr()
+
+    def fst_reduce_dev(self, pos, a, b, win, out=None, tree=None, stream=None):
+        """pos u32-as-int32 [n], a/b float64 [n], win uint8 [n_win*32] (WIN_DTYPE bytes) on the GPU.
+        Returns (out uint8 [n_win*40], tree).  Asynchronous on `stream`."""
+        import torch
+        n = a.numel()
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        tb = self.tree_bytes(PGT_STAT_FST, n)
+        if tree is None:
+            tree = torch.empty(tb, dtype=torch.uint8, device=a.device)
+        if out is None:
+            out = torch.empty(n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=a.device)
+        self._check(self._lib.pgt_fst_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(a, torch.float64, "a"),
+            self._dev(b, torch.float64, "b"), n, self._dev(win, torch.uint8, "win"), n_win,
+            self._dev(out, torch.uint8, "out"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
+            self._stream(stream)))
+        return out, tree
+
+    def fst_reduce_pairs_dev(self, pos, a_list, b_list, win, out=None, tree=None, stream=None):
+        import torch
+        n = a_list[0].numel()
+        n_pairs = len(a_list)
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        tb = self.tree_bytes(PGT_STAT_FST, n) * n_pairs
+        if tree is None:
+            tree = torch.empty(tb, dtype=torch.uint8, device=pos.device)
+        if out is None:
+            out = torch.empty(n_pairs * n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=pos.device)
+        pa = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "a") for t in a_list])
+        pb = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "b") for t in b_list])
+        self._check(self._lib.pgt_fst_reduce_pairs_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), pa, pb, n_pairs, n,
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
+        return out, tree
+
+    def het_reduce_dev(self, pos, g, win, out=None, tree=None, stream=None):
+        import torch
+        n = g.numel()
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        if tree is None:
+            tree = torch.empty(self.tree_bytes(PGT_STAT_HET, n), dtype=torch.uint8, device=g.device)
+        if out is None:
+            out = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=g.device)
+        self._check(self._lib.pgt_het_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(g, torch.int8, "g"), n,
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
+        return out, tree
+
+    def dxy_reduce_dev(self, pos, p1, p2, n1, n2, minind, win, out=None, tot=None, tree=None, stream=None):
+        import torch
+        n = p1.numel()
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        if tree is None:
+            tree = torch.empty(self.tree_bytes(PGT_STAT_DXY, n), dtype=torch.uint8, device=p1.device)
+        if out is None:
+            out = torch.empty(n_win * DXY_ROW_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
+        if tot is None:
+            tot = torch.empty(DXY_TOTAL_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
+        self._check(self._lib.pgt_dxy_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
+            self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
+            n, int(minind), self._dev(win, torch.uint8, "win") if n_win else None, n_win,
+            self._dev(out, torch.uint8, "out") if n_win else None, self._dev(tot, torch.uint8, "tot"),
+            self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
+        return out, tot, tree
+
+    # ---- per-kernel timing ------------------------------------------------------------------
+    def set_profiling(self, enabled: bool):
+        self._check(self._lib.pgt_set_profiling(self._ctx, int(enabled)))
+
+    def last_kernel_ms(self):
+        b, q = C.c_float(0), C.c_float(0)
+        self._check(self._lib.pgt_last_kernel_ms(self._ctx, C.byref(b), C.byref(q)))
+        return b.value, q.value
+
+
+def rows_from_device(t, dtype: np.dtype) -> np.ndarray:
+    """uint8 CUDA tensor of packed rows -> numpy structured array (synchronises)."""
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=dtype)
+
+
+def windows_to_device(win: np.ndarray, device):
+    import torch
+    raw = np.ascontiguousarray(win, dtype=WIN_DTYPE).view(np.uint8)
+    return torch.from_numpy(raw.copy()).to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# the three tools over in-memory columns
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class WindowResult:
+    win: np.ndarray   # WIN_DTYPE rows (label_run indexes the chromosome runs)
+    rows: np.ndarray  # per-tool row dtype
+    total: object = None  # dxy only: DXY_TOTAL_DTYPE scalar
+
+
+def _own_ctx(ctx):
+    return (Context(), True) if ctx is None else (ctx, False)
+
+
+def fst_window(chr_ids, pos, a, b, W: int = 1, S: int = 1, ctx: Context | None = None) -> WindowResult:
+    """fstWindow.cpp:109-155 over columns: rows are (start, end, mid, n, fst)."""
+    win = build_windows_sites(run_lengths(chr_ids), W, S)
+    ctx, own = _own_ctx(ctx)
+    try:
+        return WindowResult(win, ctx.fst_reduce(pos, a, b, win))
+    finally:
+        if own:
+            ctx.close()
+
+
+def het_window(chr_ids, pos, g, W: int = 1, S: int = 1, ctx: Context | None = None) -> WindowResult:
+    """hetWindow.cpp:107-153 over columns; genotypes are clipped to int8 (only `>= 0` and `== 1`
+    matter, hetWindow.cpp:78-80)."""
+    win = build_windows_sites(run_lengths(chr_ids), W, S)
+    g8 = np.clip(np.asarray(g), -128, 127).astype(np.int8)
+    ctx, own = _own_ctx(ctx)
+    try:
+        return WindowResult(win, ctx.het_reduce(pos, g8, win))
+    finally:
+        if own:
+            ctx.close()
+
+
+def dxy_window(chr_ids, pos, p1, p2, n1, n2, W: int = 0, S: int = 0, minind: int = 1, fixedsite: int = 0,
+               chr_len=None, skip_missing: int = 0, ctx: Context | None = None) -> WindowResult:
+    """dxyWindow.cpp:253-436 over two already synchronised populations.  chr_len[r] is the -sizefile
+    length of run r (required unless fixedsite).  Rows suppressed by -skip_missing are dropped, as
+    dxyWindow.cpp:189 does."""
+    if minind <= 0:
+        raise PgtError(_lib.PGT_EARG, "-minind must be at least 1")  # dxyWindow.cpp:105-108
+    if W > 0 and S < 1:
+        raise PgtError(_lib.PGT_EARG, "Must specify a -stepsize > 0 when -winsize is > 0")  # :128-131
+    if not fixedsite and chr_len is None:
+        raise PgtError(_lib.PGT_EARG, "Must supply size file unless -fixedsite 1")  # :133-136
+    if W == 0 and not fixedsite:
+        raise PgtError(_lib.PGT_EDOMAIN, "-winsize 0 needs -fixedsite 1 (the reference crashes here, SURVEY Q10)")
+    rl = run_lengths(chr_ids)
+    if W == 0:
+        win = np.zeros(0, dtype=WIN_DTYPE)
+    elif fixedsite:
+        win = build_windows_sites(rl, W, S)
+    else:
+        win = build_windows_bp(pos, rl, chr_len, W, S)
+    ctx, own = _own_ctx(ctx)
+    try:
+        rows, tot = ctx.dxy_reduce(pos, p1, p2, n1, n2, minind, win)
+    finally:
+        if own:
+            ctx.close()
+    if skip_missing:
+        keep = rows["neff"] > 0
+        win, rows = win[keep], rows[keep]
+    return WindowResult(win, rows, tot)

@@ -1,0 +1,71 @@
+"""Shared helpers for the parity tests."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# float columns are compared numerically: |x - y| <= REL * |y| + ABS (north_star: 1e-9 relative;
+# the absolute floor covers ratios of sums that cancel to ~0, SURVEY.md §7 hard parts)
+REL, ABS = 1e-9, 1e-12
+
+
+def load_golden(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def parse_table(text, kind):
+    """fst / het text -> (names per run, chr run ids, pos, cols...) exactly as the tools tokenise it."""
+    names, chr_ids, pos, c1, c2 = [], [], [], [], []
+    for line in text.splitlines():
+        if not line.strip():
+            break
+        tok = line.split()
+        if not names or names[-1] != tok[0]:
+            names.append(tok[0])
+        chr_ids.append(len(names) - 1)
+        pos.append(int(tok[1]))
+        if kind == "fst":
+            c1.append(float(tok[2]))
+            c2.append(float(tok[3]))
+        else:
+            c1.append(int(tok[2]))
+    chr_ids = np.array(chr_ids, dtype=np.uint32)
+    pos = np.array(pos, dtype=np.uint64).astype(np.uint32)
+    if kind == "fst":
+        return names, chr_ids, pos, np.array(c1, dtype=np.float64), np.array(c2, dtype=np.float64)
+    return names, chr_ids, pos, np.array(c1, dtype=np.int32)
+
+
+def parse_tsv(stdout):
+    return [ln.split("\t") for ln in stdout.splitlines() if ln]
+
+
+def close(x, y):
+    return abs(x - y) <= REL * abs(y) + ABS
+
+
+def fmt_g(x):
+    """std::cout << double with default precision == printf('%g')."""
+    s = "%g" % x
+    return s
+
+
+def assert_rows_match_tsv(names, win, rows, stat_field, count_field, tsv_rows, with_mid=True):
+    """Integers, coordinates and labels byte-exact against the reference TSV; the float column
+    numerically (the TSV carries 6 significant digits, so the tolerance is half a unit of the
+    6th digit on top of REL)."""
+    assert len(rows) == len(tsv_rows), (len(rows), len(tsv_rows))
+    for w, r, t in zip(win, rows, tsv_rows):
+        assert names[int(w["label_run"])] == t[0]
+        assert str(int(r["start"])) == t[1] and str(int(r["end"])) == t[2]
+        k = 3
+        if with_mid:
+            assert str(int(r["mid"])) == t[3]
+            k = 4
+        ref = float(t[k])
+        got = float(r[stat_field])
+        assert abs(got - ref) <= 5.1e-6 * abs(ref) + 1e-12, (got, ref)
+        assert str(int(r[count_field])) == t[k + 1]

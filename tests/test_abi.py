@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/pgtwin.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from popgenomicstools_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pgtwin.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/pgtwin.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_abi_version_and_struct_sizes():
+    lib = _lib.load()
+    assert lib.pgt_abi_version() == 1
+    # struct sizes as the header lays them out
+    assert _lib.WIN_DTYPE.itemsize == 32 and _lib.FST_ROW_DTYPE.itemsize == 40
+    assert _lib.HET_ROW_DTYPE.itemsize == 32 and _lib.DXY_ROW_DTYPE.itemsize == 24
+
+
+def test_tree_bytes_monotone_and_small():
+    lib = _lib.load()
+    for stat, col_bytes in ((_lib.PGT_STAT_FST, 16), (_lib.PGT_STAT_HET, 1), (_lib.PGT_STAT_DXY, 24)):
+        prev = 0
+        for n in (0, 1, 127, 128, 8192, 8193, 10**6, 10**8, 10**9):
+            tb = lib.pgt_tree_bytes(stat, n)
+            assert tb >= prev and tb % 256 == 0
+            prev = tb
+        assert lib.pgt_tree_bytes(stat, 10**9) < 0.02 * col_bytes * 10**9 + (1 << 20)
+    assert lib.pgt_tree_bytes(7, 100) == 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must refuse to run, loudly (no CPU path exists)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _lib.load()
+    assert not lib.pgt_open(0)
+    assert b"no CPU fallback" in lib.pgt_last_error(None)
+    from popgenomicstools_amd import Context
+    with pytest.raises(_lib.PgtError):
+        Context()
+
+
+def test_product_never_imports_oracle():
+    """Nothing under the package or include/ may reference oracle/ (the checker)."""
+    pkg = os.path.join(ROOT, "popgenomicstools_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in text and "window_oracle" not in text and "oracle_bind" not in text, f

@@ -1,0 +1,366 @@
+"""GPU: the HIP path (through the C-ABI of libpgtwin.so) against the oracle, the reference-made
+golden fixtures and size-independent properties.
+
+Bar (north_star): coordinates, counts and labels bit-exact; floats within 1e-9 relative (plus a
+1e-12 absolute floor for ratios whose numerator cancels to ~0).
+"""
+import numpy as np
+import pytest
+
+import helpers
+import synth
+from popgenomicstools_amd import _lib
+from popgenomicstools_amd._lib import FST_ROW_DTYPE, HET_ROW_DTYPE, DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, WIN_DTYPE
+from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device
+
+pytestmark = pytest.mark.gpu
+
+REL, ABS = helpers.REL, helpers.ABS
+
+
+def assert_close(got, ref, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    bad = np.abs(got - ref) > REL * np.abs(ref) + ABS
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} beyond 1e-9 (first: {got[bad][:3]} vs {ref[bad][:3]})"
+
+
+def check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S):
+    ref = oracle.fst_scan(chr_ids, pos, a, b, W, S)
+    res = pgt.fst_window(chr_ids, pos, a, b, W, S, ctx=ctx)
+    rows, win = res.rows, res.win
+    assert rows.size == ref.size
+    for f, g in (("start", "start"), ("end", "end"), ("mid", "mid"), ("n", "n")):
+        assert np.array_equal(rows[f], ref[g]), f
+    assert np.array_equal(win["label_run"], ref["label"])
+    assert_close(rows["asum"], ref["num"], "asum")
+    assert_close(rows["bsum"], ref["den"], "bsum")
+    assert_close(rows["fst"], ref["value"], "fst")
+    return rows
+
+
+def check_het(pgt, ctx, oracle, chr_ids, pos, g, W, S):
+    ref = oracle.het_scan(chr_ids, pos, g, W, S)
+    res = pgt.het_window(chr_ids, pos, g, W, S, ctx=ctx)
+    rows = res.rows
+    assert rows.size == ref.size
+    for f, gname in (("start", "start"), ("end", "end"), ("mid", "mid"), ("nonmissing", "n")):
+        assert np.array_equal(rows[f], ref[gname]), f
+    assert np.array_equal(rows["nhet"], ref["num"].astype(np.uint32))
+    assert np.array_equal(res.win["label_run"], ref["label"])
+    assert np.array_equal(rows["h"], ref["value"])  # integer counts -> the one division is identical
+    return rows
+
+
+def check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, minind, fixedsite, skip, chr_len=None):
+    ref, rtot = oracle.dxy_scan(chr_ids, pos, p1, p2, n1, n2, W, S, minind, fixedsite, skip, chr_len)
+    ref = ref[ref["printed"] == 1]
+    res = pgt.dxy_window(chr_ids, pos, p1, p2, n1, n2, W, S, minind, fixedsite, chr_len, skip, ctx=ctx)
+    rows = res.rows
+    assert rows.size == ref.size
+    assert np.array_equal(rows["start"], ref["start"]) and np.array_equal(rows["end"], ref["end"])
+    assert np.array_equal(rows["neff"], ref["n"]) and np.array_equal(rows["nskip"], ref["nskip"])
+    assert np.array_equal(res.win["label_run"], ref["label"])
+    assert_close(rows["sum"], ref["value"], "dxy sum")
+    assert int(res.total["neff"]) == int(rtot["neff"]) and int(res.total["nskip"]) == int(rtot["nskip"])
+    assert_close([res.total["sum"]], [rtot["sum"]], "dxy total")
+    return rows
+
+
+# ---------------------------------------------------------------------------------------------
+# fst
+# ---------------------------------------------------------------------------------------------
+def test_fst_golden_fixtures(pgt, ctx):
+    """Rows against the TSV printed by the unmodified reference binary."""
+    cases = helpers.load_golden("ref_random.json")["cases"] + helpers.load_golden("ref_kat.json")["cases"]
+    n = 0
+    for c in cases:
+        if c["tool"] != "fstWindow":
+            continue
+        names, chr_ids, pos, a, b = helpers.parse_table(c["input"], "fst")
+        res = pgt.fst_window(chr_ids, pos, a, b, c["W"], c["S"], ctx=ctx)
+        helpers.assert_rows_match_tsv(names, res.win, res.rows, "fst", "n", helpers.parse_tsv(c["stdout"]))
+        n += 1
+    assert n > 60
+
+
+def test_fst_config1_golden(pgt, ctx):
+    g = helpers.load_golden("ref_config1.json")
+    rng = np.random.default_rng(g["seed"])
+    chr_ids, pos = synth.chromosomes(rng, g["n"], g["n_chr"])
+    a, b = synth.fst_columns(rng, g["n"])
+    names = [f"chr{i + 1}" for i in range(g["n_chr"])]
+    for run in g["runs"]:
+        res = pgt.fst_window(chr_ids, pos, a, b, run["W"], run["S"], ctx=ctx)
+        helpers.assert_rows_match_tsv(names, res.win, res.rows, "fst", "n", helpers.parse_tsv(run["stdout"]))
+
+
+@pytest.mark.parametrize("n,n_chr,W,S", [
+    (1, 1, 1, 1), (2, 1, 2, 1), (127, 1, 5, 5), (128, 1, 128, 128), (129, 2, 128, 1), (8191, 1, 100, 50),
+    (8192, 1, 8192, 8192), (8193, 3, 4096, 4096), (16384, 1, 16384, 1000), (20000, 4, 7, 3),
+    (100_000, 20, 50_000, 10_000), (300_000, 7, 50_000, 10_000), (300_000, 7, 1000, 1), (1_000_003, 5, 600_000, 250_000),
+])
+def test_fst_vs_oracle(pgt, ctx, oracle, n, n_chr, W, S):
+    rng = np.random.default_rng(n * 31 + W)
+    chr_ids, pos = synth.chromosomes(rng, n, n_chr, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    rows = check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S)
+    if S <= W and n > W:
+        assert rows.size > 0
+
+
+def test_fst_random_small_sweep(pgt, ctx, oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(150):
+        n = int(rng.integers(1, 3000))
+        W = int(rng.integers(1, 400))
+        S = int(rng.integers(1, W + 1))
+        chr_ids, pos = synth.chromosomes(rng, n, int(rng.integers(1, min(n, 6) + 1)), equal=False)
+        a, b = synth.fst_columns(rng, n)
+        check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S)
+
+
+def test_fst_edge_values(pgt, ctx, oracle):
+    # Q6 zero denominator, negative zero numerator, cancellation, Q4 midpoint wrap
+    chr_ids = np.zeros(6, dtype=np.uint32)
+    pos = np.array([5, 6, 7, 3_000_000_000, 4_000_000_000, 4_100_000_000], dtype=np.uint64).astype(np.uint32)
+    a = np.array([0.1, -0.05, -0.0, -0.0, 0.25, -0.25])
+    b = np.array([0.0, 0.0, 0.5, 0.5, 0.0, 0.0])
+    for W, S in [(2, 1), (1, 1), (3, 2), (6, 6)]:
+        rows = check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S)
+        assert not np.signbit(rows["fst"]).any()  # the reference never prints -0
+    rows = check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, 2, 1)
+    assert rows["mid"][3] == (3_000_000_000 + 4_000_000_000) % 2**32 // 2
+
+
+def test_fst_empty_inputs(pgt, ctx):
+    res = pgt.fst_window(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0), np.zeros(0), 5, 2, ctx=ctx)
+    assert res.rows.size == 0
+    res = pgt.fst_window(np.zeros(3, np.uint32), np.arange(3, dtype=np.uint32), np.ones(3), np.ones(3), 5, 2, ctx=ctx)
+    assert res.rows.size == 0  # N <= W-S prints nothing (Q2)
+
+
+def test_fst_argument_errors(pgt, ctx):
+    pos = np.arange(10, dtype=np.uint32)
+    win = np.zeros(1, dtype=WIN_DTYPE)
+    win["lo"], win["hi"] = 0, 11  # beyond the columns
+    with pytest.raises(_lib.PgtError):
+        ctx.fst_reduce(pos, np.ones(10), np.ones(10), win)
+    win["lo"], win["hi"] = 5, 4
+    with pytest.raises(_lib.PgtError):
+        ctx.fst_reduce(pos, np.ones(10), np.ones(10), win)
+    with pytest.raises(_lib.PgtError):
+        pgt.fst_window(np.zeros(10, np.uint32), pos, np.ones(10), np.ones(10), 3, 4, ctx=ctx)  # S > W
+
+
+# ---------------------------------------------------------------------------------------------
+# het
+# ---------------------------------------------------------------------------------------------
+def test_het_golden_fixtures(pgt, ctx):
+    cases = helpers.load_golden("ref_random.json")["cases"] + helpers.load_golden("ref_kat.json")["cases"]
+    n = 0
+    for c in cases:
+        if c["tool"] != "hetWindow":
+            continue
+        names, chr_ids, pos, g = helpers.parse_table(c["input"], "het")
+        res = pgt.het_window(chr_ids, pos, g, c["W"], c["S"], ctx=ctx)
+        helpers.assert_rows_match_tsv(names, res.win, res.rows, "h", "nonmissing", helpers.parse_tsv(c["stdout"]))
+        n += 1
+    assert n > 60
+
+
+@pytest.mark.parametrize("n,n_chr,W,S", [
+    (1, 1, 1, 1), (1023, 1, 10, 3), (1024, 1, 1024, 1024), (1025, 2, 1000, 1), (65535, 1, 5000, 2500),
+    (65536, 1, 65536, 65536), (65537, 3, 30000, 10000), (200_000, 20, 50_000, 10_000), (5_000_000, 9, 4_500_000, 250_000),
+])
+def test_het_vs_oracle(pgt, ctx, oracle, n, n_chr, W, S):
+    rng = np.random.default_rng(n + 7 * S)
+    chr_ids, pos = synth.chromosomes(rng, n, n_chr, equal=False)
+    g = synth.het_column(rng, n)
+    g[rng.integers(0, n, size=max(1, n // 50))] = rng.integers(-5, 9, size=max(1, n // 50))  # other codes: >=0 is non-missing
+    check_het(pgt, ctx, oracle, chr_ids, pos, g, W, S)
+
+
+# ---------------------------------------------------------------------------------------------
+# dxy
+# ---------------------------------------------------------------------------------------------
+def test_dxy_known_answers(pgt, ctx):
+    k = helpers.load_golden("dxy_kat.json")
+    names = [r[0] for r in k["sizes"]]
+    chr_ids = np.array([names.index(r[0]) for r in k["pop1"]], dtype=np.uint32)
+    pos = np.array([r[1] for r in k["pop1"]], dtype=np.uint32)
+    p1 = np.array([r[2] for r in k["pop1"]]); n1 = np.array([r[3] for r in k["pop1"]], dtype=np.int32)
+    p2 = np.array([r[2] for r in k["pop2"]]); n2 = np.array([r[3] for r in k["pop2"]], dtype=np.int32)
+    chr_len = np.array([r[1] for r in k["sizes"]], dtype=np.uint32)
+    for c in k["cases"]:
+        res = pgt.dxy_window(chr_ids, pos, p1, p2, n1, n2, c["winsize"], c["stepsize"], k["minind"],
+                             c["fixedsite"], chr_len, c["skip_missing"], ctx=ctx)
+        lines = "".join(f"{names[int(w['label_run'])]}\t{int(r['start'])}\t{int(r['end'])}\t{helpers.fmt_g(r['sum'])}\t{int(r['neff'])}\t{int(r['nskip'])}\n"
+                        for w, r in zip(res.win, res.rows))
+        total = f"{helpers.fmt_g(res.total['sum'])}\t{int(res.total['neff'])}\t{int(res.total['nskip'])}\n"
+        if c["winsize"] == 0:
+            assert total == c["stdout"] and lines == ""
+        else:
+            assert lines == c["stdout"] and total == c["stderr"]
+
+
+@pytest.mark.parametrize("fixedsite", [1, 0])
+def test_dxy_vs_oracle_random(pgt, ctx, oracle, fixedsite):
+    rng = np.random.default_rng(3 + fixedsite)
+    for trial in range(60):
+        n_runs = int(rng.integers(1, 5))
+        pos_l, chr_l, len_l = [], [], []
+        for r in range(n_runs):
+            L = int(rng.integers(1, 4000))
+            k = int(rng.integers(1, min(L, 700) + 1))
+            p = np.sort(rng.choice(np.arange(1, L + 1), size=k, replace=False))
+            pos_l.append(p); chr_l.append(np.full(k, r)); len_l.append(L)
+        pos = np.concatenate(pos_l).astype(np.uint32)
+        chr_ids = np.concatenate(chr_l).astype(np.uint32)
+        p1, p2, n1, n2 = synth.dxy_columns(rng, pos.size)
+        W = int(rng.integers(1, 900)); S = int(rng.integers(1, W + 1))
+        check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, 5, fixedsite, int(rng.integers(0, 2)),
+                  np.array(len_l, dtype=np.uint32))
+
+
+def test_dxy_large_and_global(pgt, ctx, oracle):
+    rng = np.random.default_rng(8)
+    n = 400_000
+    chr_ids, pos = synth.chromosomes(rng, n, 6, equal=False)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, 50_000, 10_000, 5, 1, 0)
+    check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, 0, 0, 5, 1, 0)  # -winsize 0: global only
+    chr_len = np.array([int(pos[chr_ids == c].max()) + 17 for c in range(6)], dtype=np.uint32)
+    check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, 50_000, 10_000, 5, 0, 1, chr_len)
+
+
+def test_dxy_site_value_is_bitwise_the_host_formula(pgt, ctx):
+    """-winsize 1 -stepsize 1 exposes the per-site value: it must equal p1*(1-p2)+p2*(1-p1) computed
+    with separately rounded products (no FMA contraction), bit for bit (dxyWindow.cpp:381)."""
+    rng = np.random.default_rng(9)
+    n = 20_000
+    p1, p2 = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    n1 = np.full(n, 9, dtype=np.int32)
+    res = pgt.dxy_window(np.zeros(n, np.uint32), np.arange(1, n + 1, dtype=np.uint32), p1, p2, n1, n1, 1, 1, 1, 1, ctx=ctx)
+    assert np.array_equal(res.rows["sum"], p1 * (1.0 - p2) + p2 * (1.0 - p1))
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident entry points, properties at scale
+# ---------------------------------------------------------------------------------------------
+def _device_fst(ctx, pos, a, b, win):
+    import torch
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(pos.view(np.int32)).to(dev)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    out, tree = ctx.fst_reduce_dev(tp, ta, tb, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    return rows_from_device(out, FST_ROW_DTYPE)
+
+
+def test_device_api_equals_host_api_bitwise(pgt, ctx):
+    rng = np.random.default_rng(21)
+    n = 700_001
+    chr_ids, pos = synth.chromosomes(rng, n, 5, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    host = ctx.fst_reduce(pos, a, b, win)
+    dev = _device_fst(ctx, pos, a, b, win)
+    assert host.tobytes() == dev.tobytes()
+    assert _device_fst(ctx, pos, a, b, win).tobytes() == dev.tobytes()  # idempotent, deterministic
+
+
+def test_profiling_reports_both_kernels(pgt, ctx):
+    rng = np.random.default_rng(22)
+    n = 2_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4)
+    a, b = synth.fst_columns(rng, n)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    ctx.set_profiling(True)
+    try:
+        _device_fst(ctx, pos, a, b, win)
+        build_ms, query_ms = ctx.last_kernel_ms()
+    finally:
+        ctx.set_profiling(False)
+    assert 0 < build_ms < 50 and 0 < query_ms < 50
+
+
+def test_pairs_equal_singles_bitwise(pgt, ctx):
+    import torch
+    rng = np.random.default_rng(23)
+    n, n_pairs = 300_000, 5
+    chr_ids, pos = synth.chromosomes(rng, n, 3, equal=False)
+    cols = [synth.fst_columns(rng, n) for _ in range(n_pairs)]
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 20_000, 5_000)
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(pos.view(np.int32)).to(dev)
+    ta = [torch.from_numpy(c[0]).to(dev) for c in cols]
+    tb = [torch.from_numpy(c[1]).to(dev) for c in cols]
+    out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+    for p in range(n_pairs):
+        single = ctx.fst_reduce(pos, cols[p][0], cols[p][1], win)
+        assert rows[p].tobytes() == single.tobytes()
+
+
+def test_sharded_equals_single_bitwise(pgt, ctx):
+    """The multi-GPU plan on one GPU: every shard reduced on its own columns gives, concatenated,
+    exactly the bytes of the single-GPU run (shard starts are tree-node aligned)."""
+    from popgenomicstools_amd.distributed import shard_windows
+    rng = np.random.default_rng(24)
+    n = 1_500_000
+    chr_ids, pos = synth.chromosomes(rng, n, 11, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    single = ctx.fst_reduce(pos, a, b, win)
+    for world in (2, 3, 8):
+        parts = []
+        for rank in range(world):
+            s, local, _ = shard_windows(win, rank, world)
+            lo, hi = int(s["site_lo"]), int(s["site_hi"])
+            parts.append(ctx.fst_reduce(pos[lo:hi], a[lo:hi], b[lo:hi], local))
+        assert np.concatenate(parts).tobytes() == single.tobytes()
+
+
+def test_full_size_properties(pgt, ctx):
+    """10^8 sites (BASELINE configs[1]) generated on the device: properties that need no oracle.
+    (1) scaling a and b by 2 is exact in binary floating point: sums double bit for bit, fst is unchanged;
+    (2) non-overlapping windows: the window sums add up to the genome total within 1e-9;
+    (3) coordinates: start/end/mid/n follow pos and the table exactly."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, n_chr, W, S = 100_000_000, 20, 50_000, 10_000
+    gen = torch.Generator(device=dev).manual_seed(12345)
+    b = torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 0.3 * 1e6) / 1e6
+    a = torch.round(b * (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 0.7 - 0.1) * 1e6) / 1e6
+    per = n // n_chr
+    pos = torch.randint(1, 60, (n_chr, per), generator=gen, device=dev, dtype=torch.int32).cumsum(1, dtype=torch.int32).reshape(-1)
+    run_len = np.full(n_chr, per, dtype=np.uint64)
+    win = pgt.build_windows_sites(run_len, W, S)
+    wt = windows_to_device(win, dev)
+    out, tree = ctx.fst_reduce_dev(pos, a, b, wt)
+    out2, _ = ctx.fst_reduce_dev(pos, a * 2.0, b * 2.0, wt)
+    torch.cuda.synchronize()
+    r1, r2 = rows_from_device(out, FST_ROW_DTYPE), rows_from_device(out2, FST_ROW_DTYPE)
+    assert r1.size == win.size and win.size > n_chr * ((per - W) // S)
+    assert np.array_equal(r2["asum"], 2.0 * r1["asum"]) and np.array_equal(r2["bsum"], 2.0 * r1["bsum"])
+    assert np.array_equal(r2["fst"], r1["fst"])
+    # coordinates
+    hpos = pos.cpu().numpy().view(np.uint32)
+    assert np.array_equal(r1["start"], hpos[win["lo"]]) and np.array_equal(r1["end"], hpos[win["hi"] - 1])
+    assert np.array_equal(r1["mid"], ((r1["start"].astype(np.uint64) + r1["end"]) % 2**32 // 2).astype(np.uint32))
+    assert np.array_equal(r1["n"], (win["hi"] - win["lo"]).astype(np.uint32))
+    # a sample of windows against float64 sums done by torch (independent code path)
+    for i in np.linspace(0, win.size - 1, 25).astype(int):
+        lo, hi = int(win["lo"][i]), int(win["hi"][i])
+        assert_close([r1["asum"][i]], [float(a[lo:hi].sum())], "asum sample")
+        assert_close([r1["bsum"][i]], [float(b[lo:hi].sum())], "bsum sample")
+    # non-overlapping cover
+    win_t = pgt.build_windows_sites(run_len, W, W)
+    out_t, _ = ctx.fst_reduce_dev(pos, a, b, windows_to_device(win_t, dev), tree=tree)
+    torch.cuda.synchronize()
+    rt = rows_from_device(out_t, FST_ROW_DTYPE)
+    assert int(rt["n"].astype(np.int64).sum()) == n
+    assert_close([rt["bsum"].sum()], [float(b.sum())], "cover bsum")
+    assert_close([rt["asum"].sum()], [float(a.sum())], "cover asum")
