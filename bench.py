@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--stepsize", type=int, default=10_000)
     ap.add_argument("--cpu-sites", type=float, default=1e7, help="sample size of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra", action="store_true",
+                    help="also time the 10^8-site configuration (BASELINE configs[1]) on the same buffers; off by "
+                         "default so that a rocprofv3 --stats average of the default command covers one size only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,7 +180,7 @@ def main():
 
     # --- the 10^8-site configuration (BASELINE configs[1]) on the same buffers, for the record
     extra = {}
-    if rank == 0 and n > 100_000_000:
+    if args.extra and rank == 0 and n > 100_000_000:
         n8 = 100_000_000
         rl8 = np.full(20, n8 // 20, dtype=np.uint64)
         win8 = windows_to_device(pgt.build_windows_sites(rl8, W, S), dev)

@@ -59,6 +59,14 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         from . import build
         build.build_lib()
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7 and /opt/rocm has another
+    # with the same SONAME; whichever loads first serves both.  If torch loads second it finds no
+    # device through the other copy, so let torch's copy load first whenever torch is installed
+    # (device tensors, streams and torch.distributed come from it anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
     lib.pgt_open.restype = vp
