@@ -1,0 +1,195 @@
+// dxyWindow (MI355X host) — sliding-window dxy from two ANGSD .mafs files (plain or gzip).
+// Same options, defaults, messages and TSV as the reference tool (dxyWindow.cpp:34-61 help,
+// :63-139 arguments, :190 row format, :429-433 genome-wide line); per-site dxy and all window
+// sums run on the GPU through include/pgtwin.h.
+//
+//   dxyWindow [options] <pop1 maf file> <pop2 maf file>      (options come BEFORE the two files)
+//
+// Site synchronisation: the reference's catch-up loops (dxyWindow.cpp:315-331) are only well
+// defined when both files list identical or nested site sets.  This host
+// computes the intersection of the two files by (chromosome run, position), which is what the
+// reference produces on that domain, and is defined outside it as well.
+#include <map>
+
+#include "host_common.h"
+
+using namespace pgthost;
+
+static void help(unsigned W, unsigned S, int minind, int fixedsite, int skip_missing) {
+    std::printf("\ndxyWindow [options] <pop1 maf file> <pop2 maf file>\n\nOptions:\n"
+                "%-14s%-8sWindow size in base pairs (0 for global calculation) [%u]\n"
+                "%-14s%-8sNumber of base pairs to progress window [%u]\n"
+                "%-14s%-8sMinimum number of individuals in each population with data [%d]\n"
+                "%-14s%-8s(1) Use fixed number of sites from MAF input for each window (window sizes may vary) or (0) constant window size [%d]\n"
+                "%-14s%-8sTwo-column TSV file with each row having (1) chromsome name (2) chromosome size in base pairs\n"
+                "%-14s%-8sDo not print windows with zero effective sites if INT=1 [%d]\n"
+                "\nNotes:\n"
+                "* -winsize 1 -stepsize 1 calculates per site dxy\n"
+                "* -sizefile is REQUIRED(!) with -fixedsite 0 (the default)\n"
+                "* Both input MAF files need to have the same chromosomes in the same order\n"
+                "* Assumes SNPs are biallelic across populations\n"
+                "* For global Dxy calculations only columns 4, 5, and 6 below are printed\n"
+                "* Input MAF files can contain all sites (including monomorphic sites) or just variable sites\n"
+                "* -fixedsite 1 -winsize 500 would for example ensure that all windows contain 500 SNPs\n"
+                "\nOutput:\n(1) chromosome\n(2) Window start\n(3) Window end\n(4) dxy\n"
+                "(5) number sites in MAF input that were analyzed\n"
+                "(6) number of sites in MAF input that were skipped due to too few individuals\n\n",
+                "-winsize", "INT", W, "-stepsize", "INT", S, "-minind", "INT", minind, "-fixedsite", "INT", fixedsite,
+                "-sizefile", "FILE", "-skip_missing", "INT", skip_missing);
+}
+
+struct Maf {
+    Runs runs;
+    std::vector<uint32_t> pos;
+    std::vector<double> freq;
+    std::vector<int32_t> nind;
+};
+
+// chr pos major minor ref freq nind — only chr, pos, freq, nind are used (dxyWindow.cpp:141-153)
+static void read_maf(const char *path, const char *which, Maf &m) {
+    std::string text;
+    if (!slurp(path, text)) die(std::string("Unable to open ") + which + " MAF file: " + path);
+    Cursor c{text.data(), text.data() + text.size()};
+    c.next_line();  // header (dxyWindow.cpp:284)
+    size_t line = 1;
+    while (c.p < c.end) {
+        ++line;
+        c.skip_blank();
+        if (c.at_eol()) break;  // dxyWindow.cpp:313
+        auto chr = c.token();
+        uint32_t p;
+        double f;
+        long long k;
+        bool ok = to_u32(c.token(), p);
+        c.token(); c.token(); c.token();  // major minor ref
+        ok = ok && to_f64(c.token(), f) && to_i64(c.token(), k);
+        if (!ok) die(std::string("dxyWindow: cannot parse MAF line ") + std::to_string(line) + " of " + path);
+        if (!(f >= 0.0 && f <= 1.0))
+            die(std::string("dxyWindow: allele frequency outside [0,1] on line ") + std::to_string(line) + " of " + path);
+        m.runs.add(chr.first, chr.second);
+        m.pos.push_back(p);
+        m.freq.push_back(f);
+        m.nind.push_back((int32_t)std::max<long long>(std::min<long long>(k, INT32_MAX), INT32_MIN));
+        c.next_line();
+    }
+}
+
+int main(int argc, char **argv) {
+    uint32_t W = 0, S = 0;  // dxyWindow.cpp:529-534
+    int minind = 1, fixedsite = 0, skip_missing = 0;
+    const char *sizefile = nullptr;
+    if (argc < 3) {
+        help(W, S, minind, fixedsite, skip_missing);
+        return 0;
+    }
+    // the last two arguments are the MAF files; option/value pairs precede them (dxyWindow.cpp:97-126)
+    for (int i = 1; i < argc - 2; i += 2) {
+        const char *opt = argv[i], *val = argv[i + 1];
+        if (!std::strcmp(opt, "-winsize")) W = (uint32_t)std::atoi(val);
+        else if (!std::strcmp(opt, "-stepsize")) S = (uint32_t)std::atoi(val);
+        else if (!std::strcmp(opt, "-minind")) {
+            minind = std::atoi(val);
+            if (minind <= 0) die("-minind must be at least 1");
+        } else if (!std::strcmp(opt, "-sizefile")) sizefile = val;
+        else if (!std::strcmp(opt, "-fixedsite")) fixedsite = std::atoi(val);
+        else if (!std::strcmp(opt, "-skip_missing")) skip_missing = std::atoi(val);
+        else die(std::string("Unknown command: ") + opt);
+    }
+    if (W > 0 && S < 1) die("Must specify a -stepsize > 0 when -winsize is > 0");
+    if (!fixedsite && !sizefile) die("Must supply size file unless -fixedsite 1");
+    if (W > 0 && S > W) die("-stepsize must not exceed -winsize");                      // reference: crash (Q9)
+    if (W == 0 && !fixedsite) die("-winsize 0 (global dxy) requires -fixedsite 1");      // reference: crash (Q10)
+
+    std::map<std::string, uint32_t> chrsize;  // dxyWindow.cpp:155-170
+    if (!fixedsite) {
+        std::string text;
+        if (!slurp(sizefile, text)) die(std::string("Unable to open sizefile: ") + sizefile);
+        Cursor c{text.data(), text.data() + text.size()};
+        while (c.p < c.end) {
+            auto name = c.token();
+            uint32_t len = 0;
+            if (name.first == name.second || !to_u32(c.token(), len) || len == 0)
+                die("Unable to correctly parse chromosome size file");
+            chrsize.insert({std::string(name.first, name.second), len});
+            c.next_line();
+        }
+    }
+
+    Maf m1, m2;
+    read_maf(argv[argc - 2], "Pop1", m1);
+    read_maf(argv[argc - 1], "Pop2", m2);
+    if (m1.pos.empty() || m2.pos.empty()) die("dxyWindow: a MAF file holds no sites");
+    if (m1.runs.name[0] != m2.runs.name[0]) die("Chromosomes in MAF files differ");  // dxyWindow.cpp:295-298
+
+    // intersection by (run, position)
+    Runs runs;
+    std::vector<uint32_t> pos;
+    std::vector<double> p1, p2;
+    std::vector<int32_t> n1, n2;
+    {
+        size_t r1 = 0, r2 = 0, o1 = 0, o2 = 0;
+        while (r1 < m1.runs.name.size() && r2 < m2.runs.name.size()) {
+            const std::string &c1 = m1.runs.name[r1], &c2 = m2.runs.name[r2];
+            if (c1 != c2) {  // skip the run that the other file does not have next
+                bool later_in_1 = false;
+                for (size_t k = r1 + 1; k < m1.runs.name.size() && !later_in_1; ++k) later_in_1 = m1.runs.name[k] == c2;
+                if (later_in_1) { o1 += m1.runs.len[r1]; ++r1; } else { o2 += m2.runs.len[r2]; ++r2; }
+                continue;
+            }
+            size_t i = o1, j = o2;
+            const size_t e1 = o1 + m1.runs.len[r1], e2 = o2 + m2.runs.len[r2];
+            while (i < e1 && j < e2) {
+                if (m1.pos[i] < m2.pos[j]) ++i;
+                else if (m2.pos[j] < m1.pos[i]) ++j;
+                else {
+                    runs.add(c1.data(), c1.data() + c1.size());
+                    pos.push_back(m1.pos[i]);
+                    p1.push_back(m1.freq[i]); p2.push_back(m2.freq[j]);
+                    n1.push_back(m1.nind[i]); n2.push_back(m2.nind[j]);
+                    ++i; ++j;
+                }
+            }
+            o1 = e1; o2 = e2; ++r1; ++r2;
+        }
+    }
+    if (pos.empty()) die("dxyWindow: the two MAF files share no site");
+
+    std::vector<pgt_win> win;
+    if (W > 0) {
+        size_t n_win = 0;
+        if (fixedsite) {
+            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+            win.resize(n_win);
+            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+        } else {
+            std::vector<uint32_t> chr_len(runs.name.size());
+            for (size_t r = 0; r < runs.name.size(); ++r) {
+                auto it = chrsize.find(runs.name[r]);
+                if (it == chrsize.end()) die("Unable to determine size for " + runs.name[r]);  // dxyWindow.cpp:340-343
+                chr_len[r] = it->second;
+            }
+            check(pgt_build_windows_bp(pos.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+            win.resize(n_win);
+            check(pgt_build_windows_bp(pos.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+        }
+    }
+
+    pgt_ctx *ctx = open_or_die();
+    std::vector<pgt_dxy_row> rows(win.size());
+    pgt_dxy_total tot{};
+    check(pgt_dxy_reduce(ctx, pos.data(), p1.data(), p2.data(), n1.data(), n2.data(), pos.size(), minind, win.data(),
+                         win.size(), rows.data(), &tot), ctx);
+    pgt_close(ctx);
+
+    static char obuf[1 << 20];
+    std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
+    for (size_t i = 0; i < win.size(); ++i)
+        if (rows[i].neff > 0 || !skip_missing)  // dxyWindow.cpp:189-191
+            std::printf("%s\t%u\t%u\t%g\t%u\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start, rows[i].end,
+                        rows[i].sum, rows[i].neff, rows[i].nskip);
+    std::fflush(stdout);
+    // genome-wide line: stdout for the global run, stderr beside windows (dxyWindow.cpp:429-433)
+    std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff,
+                 (unsigned long long)tot.nskip);
+    return 0;
+}

@@ -1,0 +1,72 @@
+// hetWindow (MI355X host) — sliding-window individual heterozygosity = #het / #non-missing.
+// Same command line and TSV as the reference tool (hetWindow.cpp:20-32 usage, :34-64 arguments,
+// :87 row format: column 6 is the NON-MISSING count); reduction on the GPU via include/pgtwin.h.
+//
+//   hetWindow <genotypes file> [window size (sites)] [step size (sites)]
+//   input lines:  chr  pos  g   (g: 0/1/2, negative = missing)
+#include <algorithm>
+
+#include "host_common.h"
+
+using namespace pgthost;
+
+static void usage(unsigned W, unsigned S) {
+    std::printf("\nUsage:\n"
+                "hetWindow [genotypes file] [window size (number sites)] [step size (number sites)]\n"
+                "default window size: %u\ndefault step size: %u\n\n"
+                "Output:\n(1) chromosome\n(2) window start\n(3) window end\n(4) window midpoint position\n"
+                "(5) heterozygosity\n(6) Number sites in window\n\n", W, S);
+}
+
+int main(int argc, char **argv) {
+    uint32_t W = 1, S = 1;  // hetWindow.cpp:159-160
+    if (argc < 2) {
+        usage(W, S);
+        return 0;
+    }
+    std::string text;
+    if (!slurp(argv[1], text)) die(std::string("Unable to open genotypes file ") + argv[1]);
+    parse_window_args(argc, argv, W, S);
+
+    Runs runs;
+    std::vector<uint32_t> pos;
+    std::vector<int8_t> g;
+    const size_t guess = text.size() / 12 + 16;
+    pos.reserve(guess); g.reserve(guess);
+    Cursor c{text.data(), text.data() + text.size()};
+    size_t line = 0;
+    while (c.p < c.end) {
+        ++line;
+        c.skip_blank();
+        if (c.at_eol()) break;  // hetWindow.cpp:123
+        auto chr = c.token();
+        uint32_t p;
+        long long v;
+        if (!to_u32(c.token(), p) || !to_i64(c.token(), v))
+            die("hetWindow: cannot parse 'chr pos genotype' on line " + std::to_string(line) + " of " + argv[1]);
+        runs.add(chr.first, chr.second);
+        pos.push_back(p);
+        // only `>= 0` and `== 1` are ever tested (hetWindow.cpp:78-80): clamping to int8 keeps both
+        g.push_back((int8_t)std::clamp<long long>(v, -128, 127));
+        c.next_line();
+    }
+    std::string().swap(text);
+
+    size_t n_win = 0;
+    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+    if (n_win == 0) return 0;
+    std::vector<pgt_win> win(n_win);
+    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+
+    pgt_ctx *ctx = open_or_die();
+    std::vector<pgt_het_row> rows(n_win);
+    check(pgt_het_reduce(ctx, pos.data(), g.data(), pos.size(), win.data(), n_win, rows.data()), ctx);
+    pgt_close(ctx);
+
+    static char obuf[1 << 20];
+    std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
+    for (size_t i = 0; i < n_win; ++i)
+        std::printf("%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start, rows[i].end,
+                    rows[i].mid, rows[i].h, rows[i].nonmissing);
+    return 0;
+}

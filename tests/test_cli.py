@@ -1,0 +1,181 @@
+"""The retained C++ hosts (popgenomicstools_amd/bin/{fstWindow,hetWindow,dxyWindow}): same argv,
+TSV and exit codes as the reference tools.  Argument handling is checked on CPU (it happens before
+any GPU use); TSV parity against the reference-made goldens needs the GPU."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "popgenomicstools_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def hosts():
+    from popgenomicstools_amd import build
+    build.build_lib()
+    build.build_hosts()
+    return {t: os.path.join(BIN, t) for t in ("fstWindow", "hetWindow", "dxyWindow")}
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=120, **kw)
+
+
+# ---- CPU: command-line behaviour (fstWindow.cpp:37-67,164-170; dxyWindow.cpp:63-139,537-538) ----
+def test_usage_exits_zero(hosts):
+    for tool in ("fstWindow", "hetWindow"):
+        r = run([hosts[tool]])
+        assert r.returncode == 0 and "default window size: 1" in r.stdout and "default step size: 1" in r.stdout
+    r = run([hosts["dxyWindow"]])
+    assert r.returncode == 0 and "-skip_missing" in r.stdout and "[0]" in r.stdout
+    assert run([hosts["dxyWindow"], "onlyone.mafs"]).returncode == 0  # argc < 3 -> help, exit 0
+
+
+def test_bad_arguments_exit_255(hosts, tmp_path):
+    f = tmp_path / "in.txt"
+    f.write_text("c1\t1\t0.1\t0.2\n")
+    for tool in ("fstWindow", "hetWindow"):
+        assert run([hosts[tool], str(tmp_path / "missing.txt")]).returncode == 255
+        r = run([hosts[tool], str(f), "0"])
+        assert r.returncode == 255 and "Window size must be a positive integer" in r.stderr
+        r = run([hosts[tool], str(f), "abc", "1"])
+        assert r.returncode == 255
+        r = run([hosts[tool], str(f), "3", "0"])  # the reference warns, then crashes (Q9)
+        assert r.returncode == 255 and "Step size must be a positive integer" in r.stderr
+        assert run([hosts[tool], str(f), "3", "4"]).returncode == 255  # S > W: the reference segfaults
+    d = hosts["dxyWindow"]
+    r = run([d, "-bogus", "1", str(f), str(f)])
+    assert r.returncode == 255 and "Unknown command: -bogus" in r.stderr
+    r = run([d, "-minind", "0", "-fixedsite", "1", str(f), str(f)])
+    assert r.returncode == 255 and "-minind must be at least 1" in r.stderr
+    r = run([d, "-winsize", "5", "-fixedsite", "1", str(f), str(f)])
+    assert r.returncode == 255 and "Must specify a -stepsize > 0" in r.stderr
+    r = run([d, "-winsize", "5", "-stepsize", "1", str(f), str(f)])
+    assert r.returncode == 255 and "Must supply size file unless -fixedsite 1" in r.stderr
+    r = run([d, "-fixedsite", "1", str(tmp_path / "nope.mafs"), str(f)])
+    assert r.returncode == 255 and "Unable to open Pop1 MAF file" in r.stderr
+
+
+def test_unparsable_line_is_refused(hosts, tmp_path):
+    f = tmp_path / "bad.txt"
+    f.write_text("c1\t1\t0.1\t0.2\nc1\t2\tnan_or_header\t0.2\n")
+    r = run([hosts["fstWindow"], str(f), "1", "1"])
+    assert r.returncode == 255 and "line 2" in r.stderr  # the reference would reuse stale values (Q12)
+
+
+def test_no_window_input_prints_nothing(hosts, tmp_path):
+    f = tmp_path / "short.txt"
+    f.write_text("c\t1\t0.1\t0.2\nc\t2\t0.1\t0.2\nc\t3\t0.1\t0.2\n")
+    r = run([hosts["fstWindow"], str(f), "5", "2"])
+    assert r.returncode == 0 and r.stdout == ""  # N <= W-S (Q2)
+    e = tmp_path / "empty.txt"
+    e.write_text("")
+    assert run([hosts["hetWindow"], str(e), "3", "1"]).stdout == ""
+
+
+# ---- GPU: TSV parity -------------------------------------------------------------------------
+def tsv_equal(mine, ref, float_col):
+    a, b = helpers.parse_tsv(mine), helpers.parse_tsv(ref)
+    assert len(a) == len(b), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert len(x) == len(y)
+        for k, (u, v) in enumerate(zip(x, y)):
+            if k == float_col and u != v:  # %g keeps 6 digits: allow the last printed digit to differ
+                assert abs(float(u) - float(v)) <= 1.01e-5 * abs(float(v)) + 1e-12, (x, y)
+            else:
+                assert u == v, (x, y)
+
+
+@pytest.mark.gpu
+def test_fst_het_cli_against_reference_goldens(hosts, tmp_path):
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"]
+    exact = 0
+    for i, c in enumerate(cases):
+        if i % 3 and "note" not in c:  # every third random case keeps the test short
+            continue
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        r = run([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])])
+        assert r.returncode == 0, r.stderr
+        tsv_equal(r.stdout, c["stdout"], 4)
+        exact += r.stdout == c["stdout"]
+    assert exact >= 40  # in practice every case is byte-identical
+
+
+@pytest.mark.gpu
+def test_fst_cli_config1(hosts, tmp_path, oracle):
+    import synth
+    g = helpers.load_golden("ref_config1.json")
+    rng = np.random.default_rng(g["seed"])
+    chr_ids, pos = synth.chromosomes(rng, g["n"], g["n_chr"])
+    a, b = synth.fst_columns(rng, g["n"])
+    f = tmp_path / "c1.txt"
+    oracle.write_fst_text(str(f), chr_ids, pos, a, b)
+    for runcfg in g["runs"]:
+        r = run([hosts["fstWindow"], str(f), str(runcfg["W"]), str(runcfg["S"])])
+        assert r.returncode == 0, r.stderr
+        tsv_equal(r.stdout, runcfg["stdout"], 4)
+
+
+def _write_maf(path, header, rows, gz=False):
+    text = header + "\n" + "".join(f"{c}\t{p}\tA\tC\tA\t{fr:.6f}\t{n}\n" for c, p, fr, n in rows)
+    if gz:
+        with gzip.open(path, "wt") as fh:
+            fh.write(text)
+    else:
+        open(path, "w").write(text)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gz", [False, True])
+def test_dxy_cli_known_answers(hosts, tmp_path, gz):
+    k = helpers.load_golden("dxy_kat.json")
+    m1, m2, sz = tmp_path / ("p1.mafs.gz" if gz else "p1.mafs"), tmp_path / "p2.mafs", tmp_path / "sizes.txt"
+    _write_maf(m1, k["header"], k["pop1"], gz)
+    _write_maf(m2, k["header"], k["pop2"])
+    sz.write_text("".join(f"{c}\t{n}\n" for c, n in k["sizes"]))
+    for c in k["cases"]:
+        cmd = [hosts["dxyWindow"], "-winsize", str(c["winsize"]), "-stepsize", str(c["stepsize"]),
+               "-minind", str(k["minind"]), "-fixedsite", str(c["fixedsite"]), "-skip_missing", str(c["skip_missing"])]
+        if not c["fixedsite"]:
+            cmd += ["-sizefile", str(sz)]
+        r = run(cmd + [str(m1), str(m2)])
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == c["stdout"] and r.stderr == c["stderr"]
+
+
+@pytest.mark.gpu
+def test_dxy_cli_intersects_site_sets(hosts, tmp_path, oracle):
+    """pop2 lists extra sites (nested set): rows equal the oracle run on the shared sites."""
+    rng = np.random.default_rng(4)
+    rows1, rows2, shared = [], [], []
+    for c, L in (("cA", 900), ("cB", 500)):
+        p2 = np.sort(rng.choice(np.arange(1, L + 1), size=200, replace=False))
+        keep = np.sort(rng.choice(p2, size=150, replace=False))
+        for p in p2:
+            r2 = (c, int(p), round(float(rng.uniform(0, 1)), 6), int(rng.integers(0, 9)))
+            rows2.append(r2)
+            if p in keep:
+                r1 = (c, int(p), round(float(rng.uniform(0, 1)), 6), int(rng.integers(0, 9)))
+                rows1.append(r1)
+                shared.append((r1, r2))
+    hdr = helpers.load_golden("dxy_kat.json")["header"]
+    m1, m2, s1, s2, sz = (tmp_path / n for n in ("a.mafs", "b.mafs", "sa.mafs", "sb.mafs", "sizes.txt"))
+    _write_maf(m1, hdr, rows1); _write_maf(m2, hdr, rows2)
+    _write_maf(s1, hdr, [x for x, _ in shared]); _write_maf(s2, hdr, [y for _, y in shared])
+    sz.write_text("cA\t900\ncB\t500\n")
+    for fixed in (1, 0):
+        o, e = tmp_path / "o.txt", tmp_path / "e.txt"
+        assert oracle.dxy_text(str(s1), str(s2), None if fixed else str(sz), 60, 20, 3, fixed, 1, str(o), str(e)) == 0
+        cmd = [hosts["dxyWindow"], "-winsize", "60", "-stepsize", "20", "-minind", "3", "-fixedsite", str(fixed), "-skip_missing", "1"]
+        if not fixed:
+            cmd += ["-sizefile", str(sz)]
+        r = run(cmd + [str(m1), str(m2)])
+        assert r.returncode == 0, r.stderr
+        tsv_equal(r.stdout, o.read_text(), 3)
+        tsv_equal(r.stderr, e.read_text(), 0)
