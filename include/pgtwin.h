@@ -132,6 +132,16 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
                        const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
                        void *tree, size_t tree_bytes, void *stream);
 
+/* dxyWindow + hetWindow of two genotype columns over ONE position column and ONE window table
+ * (BASELINE config 3): one build launch streams all six columns (26 B/site), one query launch
+ * answers the three tables.  tree must hold pgt_tree_bytes(PGT_STAT_DXY, n) +
+ * 2 * pgt_tree_bytes(PGT_STAT_HET, n) bytes.  Rows equal those of the separate calls bit for bit. */
+int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
+                           const int32_t *n1, const int32_t *n2, const int8_t *g1, const int8_t *g2,
+                           uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+                           pgt_dxy_row *dxy_out, pgt_dxy_total *tot, pgt_het_row *het_out1,
+                           pgt_het_row *het_out2, void *tree, size_t tree_bytes, void *stream);
+
 /* Batched population pairs sharing one position column and one window table (BASELINE
  * config 5): a[p], b[p] are HOST arrays of n_pairs DEVICE column pointers; out holds
  * n_pairs * n_win rows, pair-major; tree holds n_pairs trees (n_pairs * pgt_tree_bytes). */

@@ -209,6 +209,24 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
                       &ctx->error);
 }
 
+int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+                           const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
+                           const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
+                           pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, size_t tree_bytes, void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!p1 || !p2 || !n1 || !n2 || !g1 || !g2 || !tree || (n_win && (!win || !dxy_out || !het_out1 || !het_out2 || !pos)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: NULL argument");
+    if (!aligned16(p1) || !aligned16(p2) || !aligned16(g1) || !aligned16(g2) ||
+        (reinterpret_cast<uintptr_t>(n1) & 7u) || (reinterpret_cast<uintptr_t>(n2) & 7u))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: f64/i8 columns need 16-byte, i32 columns 8-byte alignment");
+    if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: at most 2^32-1 sites per call");
+    if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n) + 2 * pgt_tree_bytes(PGT_STAT_HET, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_dxy_het(pos, p1, p2, n1, n2, g1, g2, n, minind, win, n_win, dxy_out, tot, het_out1, het_out2, tree,
+                          stream, e.b0, e.b1, e.q1, &ctx->error);
+}
+
 /* ---------------- host-buffer entry points ---------------- */
 
 int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,

@@ -72,6 +72,12 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
                pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, void *stream, void *ev_build0,
                void *ev_build1, void *ev_query1, std::string *err);
 
+int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+                   const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
+                   const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
+                   pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, void *stream,
+                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err);
+
 // thread-local message for the ctx-less entry points
 void set_global_error(const std::string &msg);
 const std::string &global_error();

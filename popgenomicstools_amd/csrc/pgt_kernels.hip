@@ -20,6 +20,8 @@
 // Memory-bound: 2 f64 adds per 16 B, no contraction to feed MFMA (none is used).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pgt_internal.h"
 
 namespace pgt {
@@ -93,10 +95,39 @@ struct TreeView {
     int n_levels;
 };
 
+// Column loads; NT = non-temporal hint (`global_load_dwordx4 ... nt`): the columns are read exactly
+// once per pass, and in interleaved A/B runs the hint was worth +5 % (10^9 sites) to +17 % (10^8).
+template <bool NT>
+__device__ __forceinline__ double2 load16(const double2 *p) {
+    if constexpr (NT) {
+        double2 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        return v;
+    } else {
+        return *p;
+    }
+}
+__device__ __forceinline__ uint4 load16_nt(const uint4 *p) {
+    uint4 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    v.z = __builtin_nontemporal_load(&p->z);
+    v.w = __builtin_nontemporal_load(&p->w);
+    return v;
+}
+__device__ __forceinline__ int2 load8_nt(const int2 *p) {
+    int2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // BUILD, fst: level-1 {Σa,Σb} per 128 sites, level-2 per 8192 sites.        16 B/site read.
 // grid.x: waves stride over level-2 tiles; grid.y: population pair.
 // ------------------------------------------------------------------------------------------
+template <int UNROLL, bool NT, bool ABLATE_XLANE = false>
 __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2,
                                                         TreeView tv) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -116,18 +147,23 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
             const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(a + base);
             const double2 *__restrict__ pb = reinterpret_cast<const double2 *>(b + base);
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += 4) {
-                double2 va[4], vb[4];
+            for (int j = 0; j < kRadix; j += UNROLL) {
+                double2 va[UNROLL], vb[UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {  // 8 x 16-byte loads in flight per lane
-                    va[u] = pa[(j + u) * kWave + lane];
-                    vb[u] = pb[(j + u) * kWave + lane];
+                for (int u = 0; u < UNROLL; ++u) {  // 2*UNROLL x 16-byte loads in flight per lane
+                    va[u] = load16<NT>(pa + (j + u) * kWave + lane);
+                    vb[u] = load16<NT>(pb + (j + u) * kWave + lane);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double sa = wave_sum(va[u].x + va[u].y);
-                    const double sb = wave_sum(vb[u].x + vb[u].y);
-                    if (lane == j + u) { keep_a = sa; keep_b = sb; }
+                for (int u = 0; u < UNROLL; ++u) {
+                    if constexpr (ABLATE_XLANE) {  // timing-only build: wrong results, same loads
+                        keep_a += va[u].x + va[u].y;
+                        keep_b += vb[u].x + vb[u].y;
+                    } else {
+                        const double sa = wave_sum(va[u].x + va[u].y);
+                        const double sb = wave_sum(vb[u].x + vb[u].y);
+                        if (lane == j + u) { keep_a = sa; keep_b = sb; }
+                    }
                 }
             }
         } else {  // last, partial level-2 tile: guarded 8-byte loads, zero fill
@@ -158,41 +194,41 @@ __device__ __forceinline__ void het_count_word(uint32_t w, uint32_t &nonmiss, ui
     nhet += (uint32_t)__popc(y);
 }
 
-__global__ __launch_bounds__(256) void het_build_kernel(const int8_t *__restrict__ g, uint64_t n,
-                                                        uint64_t n_l2, TreeView tv) {
+// One work item = 8 leaf tiles (8192 sites, 8 KiB): 8 x 16-byte loads in flight per lane, eight
+// level-1 nodes stored by lanes 0-7.  Level 2 is derived from level 1 by tree_up_kernel: with
+// 65536-site level-2 tiles a wave-per-level-2-tile build has too few work items to fill the chip
+// (1526 at 10^8 sites; measured 0.8 TB/s), this form has 8x as many.
+constexpr int kHetChunk = 8;
+__device__ __forceinline__ void het_build_body(const int8_t *__restrict__ g, uint64_t n, uint64_t n_items,
+                                               const TreeView &tv) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     NodeHet *__restrict__ l1 = reinterpret_cast<NodeHet *>(tv.base + tv.off[0]);
-    NodeHet *__restrict__ l2 = reinterpret_cast<NodeHet *>(tv.base + tv.off[1]);
-    constexpr uint64_t kTile2 = (uint64_t)kLeafI8 * kRadix;  // 65536 sites
+    constexpr uint64_t kItem = (uint64_t)kLeafI8 * kHetChunk;  // 8192 sites
 
-    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
-        const uint64_t base = t * kTile2;
+    for (uint64_t t = wave0; t < n_items; t += n_waves) {
+        const uint64_t base = t * kItem;
         uint32_t keep_nm = 0, keep_nh = 0;
-        if (base + kTile2 <= n) {
+        if (base + kItem <= n) {
             const uint4 *__restrict__ pg = reinterpret_cast<const uint4 *>(g + base);
-#pragma unroll 1
-            for (int j = 0; j < kRadix; j += 8) {
-                uint4 w[8];
+            uint4 w[kHetChunk];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = pg[(j + u) * kWave + lane];
+            for (int u = 0; u < kHetChunk; ++u) w[u] = load16_nt(pg + u * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    uint32_t nm = 0, nh = 0;
-                    het_count_word(w[u].x, nm, nh);
-                    het_count_word(w[u].y, nm, nh);
-                    het_count_word(w[u].z, nm, nh);
-                    het_count_word(w[u].w, nm, nh);
-                    nm = wave_sum(nm);
-                    nh = wave_sum(nh);
-                    if (lane == j + u) { keep_nm = nm; keep_nh = nh; }
-                }
+            for (int u = 0; u < kHetChunk; ++u) {
+                uint32_t nm = 0, nh = 0;
+                het_count_word(w[u].x, nm, nh);
+                het_count_word(w[u].y, nm, nh);
+                het_count_word(w[u].z, nm, nh);
+                het_count_word(w[u].w, nm, nh);
+                nm = wave_sum(nm);
+                nh = wave_sum(nh);
+                if (lane == u) { keep_nm = nm; keep_nh = nh; }
             }
-        } else {
-            for (int j = 0; j < kRadix; ++j) {
+        } else {  // last, partial item: bytewise, sites beyond n count as nothing
+            for (int j = 0; j < kHetChunk; ++j) {
                 const uint64_t tile0 = base + (uint64_t)j * kLeafI8;
-                if (tile0 >= n) break;  // wave-uniform
                 uint32_t nm = 0, nh = 0;
                 for (int q = 0; q < 16; ++q) {
                     const uint64_t i = tile0 + (uint64_t)lane * 16 + q;
@@ -207,10 +243,12 @@ __global__ __launch_bounds__(256) void het_build_kernel(const int8_t *__restrict
                 if (lane == j) { keep_nm = nm; keep_nh = nh; }
             }
         }
-        l1[t * kRadix + lane] = NodeHet{keep_nm, keep_nh};
-        const uint32_t tm = wave_sum(keep_nm), th = wave_sum(keep_nh);
-        if (lane == 0) l2[t] = NodeHet{tm, th};
+        if (lane < kHetChunk) l1[t * kHetChunk + lane] = NodeHet{keep_nm, keep_nh};
     }
+}
+
+__global__ __launch_bounds__(256) void het_build_kernel(const int8_t *g, uint64_t n, uint64_t n_items, TreeView tv) {
+    het_build_body(g, n, n_items, tv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -227,11 +265,9 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
     else if (v == -9.0) acc.nskip += 1;
 }
 
-__global__ __launch_bounds__(256) void dxy_build_kernel(const double *__restrict__ p1,
-                                                        const double *__restrict__ p2,
-                                                        const int32_t *__restrict__ n1,
-                                                        const int32_t *__restrict__ n2, uint64_t n,
-                                                        int minind, uint64_t n_l2, TreeView tv) {
+__device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, const double *__restrict__ p2,
+                                               const int32_t *__restrict__ n1, const int32_t *__restrict__ n2,
+                                               uint64_t n, int minind, uint64_t n_l2, const TreeView &tv) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -253,10 +289,10 @@ __global__ __launch_bounds__(256) void dxy_build_kernel(const double *__restrict
                 int2 k1[2], k2[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    x1[u] = q1[(j + u) * kWave + lane];
-                    x2[u] = q2[(j + u) * kWave + lane];
-                    k1[u] = m1[(j + u) * kWave + lane];
-                    k2[u] = m2[(j + u) * kWave + lane];
+                    x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
+                    x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
+                    k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+                    k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -284,6 +320,29 @@ __global__ __launch_bounds__(256) void dxy_build_kernel(const double *__restrict
         const NodeDxy tot = node_wave_sum(keep);
         if (lane == 0) l2[t] = tot;
     }
+}
+
+__global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const double *p2, const int32_t *n1,
+                                                        const int32_t *n2, uint64_t n, int minind, uint64_t n_l2,
+                                                        TreeView tv) {
+    dxy_build_body(p1, p2, n1, n2, n, minind, n_l2, tv);
+}
+
+// BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
+// window table.  One launch builds all three trees: blockIdx.y = 0 dxy, 1 and 2 the genotype
+// columns.  26 B/site streamed (p1,p2 f64 + n1,n2 i32 + g1,g2 i8).
+struct DxyHetBuildArgs {
+    const double *p1, *p2;
+    const int32_t *n1, *n2;
+    const int8_t *g[2];
+    uint64_t n;
+    int minind;
+    uint64_t n_l2_dxy, n_items_het;
+    TreeView tv_dxy, tv_het[2];
+};
+__global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
+    if (blockIdx.y == 0) dxy_build_body(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy);
+    else het_build_body(f.g[blockIdx.y - 1], f.n, f.n_items_het, f.tv_het[blockIdx.y - 1]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -404,14 +463,13 @@ __device__ __forceinline__ void sum_level(typename Tr::Node &acc, const typename
 }
 
 template <class Tr>
-__global__ __launch_bounds__(256) void query_kernel(typename Tr::Args args, const uint32_t *__restrict__ pos,
-                                                    TreeView tv, const pgt_win *__restrict__ win,
-                                                    uint64_t n_win, typename Tr::Row *__restrict__ out,
-                                                    uint64_t n_sites, pgt_dxy_total *tot) {
+__device__ __forceinline__ void query_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
+                                           const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
+                                           typename Tr::Row *__restrict__ out, uint64_t n_sites,
+                                           pgt_dxy_total *tot, int pair) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const int pair = blockIdx.y;
     const typename Tr::Cols c = Tr::cols(args, pair);
     const char *tree = tv.base + (size_t)pair * tv.pair_stride;
     const uint64_t n_items = n_win + (tot ? 1 : 0);  // the extra item is the genome-wide total
@@ -461,17 +519,58 @@ __global__ __launch_bounds__(256) void query_kernel(typename Tr::Args args, cons
     }
 }
 
+template <class Tr>
+__global__ __launch_bounds__(256) void query_kernel(typename Tr::Args args, const uint32_t *pos, TreeView tv,
+                                                    const pgt_win *win, uint64_t n_win, typename Tr::Row *out,
+                                                    uint64_t n_sites, pgt_dxy_total *tot) {
+    query_body<Tr>(args, pos, tv, win, n_win, out, n_sites, tot, (int)blockIdx.y);
+}
+
+struct DxyHetQueryArgs {
+    DxyTraits::Args dxy;
+    const int8_t *g[2];
+    TreeView tv_dxy, tv_het[2];
+    pgt_dxy_row *dxy_out;
+    pgt_dxy_total *tot;
+    pgt_het_row *het_out[2];
+};
+__global__ __launch_bounds__(256) void dxy_het_query_kernel(DxyHetQueryArgs f, const uint32_t *pos, const pgt_win *win,
+                                                            uint64_t n_win, uint64_t n_sites) {
+    if (blockIdx.y == 0) {
+        query_body<DxyTraits>(f.dxy, pos, f.tv_dxy, win, n_win, f.dxy_out, n_sites, f.tot, 0);
+    } else {
+        const int k = blockIdx.y - 1;
+        query_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0);
+    }
+}
+
 inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     if (e == hipSuccess) return PGT_OK;
     if (err) *err = std::string(what) + ": " + hipGetErrorString(e);
     return PGT_EDEVICE;
 }
 
-inline unsigned build_grid(uint64_t n_l2) {
-    // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; cap at 8 resident
-    // workgroups per CU x 256 CUs and grid-stride the rest.
+// Launch geometry of the build kernels.  Defaults were chosen by interleaved A/B runs on MI355X
+// (profiles/r01/tune_build.md); the PGT_TUNE_* environment variables exist for that experiment only.
+struct BuildTuning {
+    unsigned blocks;  // workgroup cap; waves grid-stride over level-2 tiles beyond it (0 = no cap)
+    int unroll;       // leaf tiles per loop iteration: 2*unroll 16-byte loads in flight per lane
+    bool nt;          // non-temporal column loads
+};
+inline BuildTuning build_tuning() {
+    BuildTuning t{2048u, 4, true};
+    if (const char *e = std::getenv("PGT_TUNE_BUILD_BLOCKS")) t.blocks = (unsigned)std::atoi(e);
+    if (const char *e = std::getenv("PGT_TUNE_BUILD_UNROLL")) t.unroll = std::atoi(e);
+    if (const char *e = std::getenv("PGT_TUNE_BUILD_NT")) t.nt = std::atoi(e) != 0;
+    return t;
+}
+
+inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
+    // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
+    // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
     uint64_t blocks = (n_l2 + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (cap && blocks > cap) blocks = cap;
+    if (blocks > (1u << 30)) blocks = 1u << 30;
     if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
 }
@@ -483,6 +582,8 @@ inline unsigned query_grid(uint64_t n_items) {
     return (unsigned)blocks;
 }
 
+inline uint64_t het_items(uint64_t n) { return (n + (uint64_t)kLeafI8 * kHetChunk - 1) / ((uint64_t)kLeafI8 * kHetChunk); }
+
 TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride) {
     TreeView tv{};
     tv.base = static_cast<char *>(tree);
@@ -492,10 +593,14 @@ TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride) {
     return tv;
 }
 
+// Levels above what the build kernel wrote itself: slot k-1 -> slot k for k = first..n_levels-1.
+// first = 2 when the build wrote levels 1 and 2 (fst, dxy), 1 when it wrote level 1 only (het);
+// n_level1 = level-1 nodes actually written (the padding beyond them is never read).
 template <class Node>
-int launch_upper(const TreeLayout &tl, const TreeView &tv, unsigned n_pairs, hipStream_t s, std::string *err) {
-    for (int k = 2; k < tl.n_levels; ++k) {  // slot k-1 -> slot k
-        const uint64_t n_child = tl.count[k - 1], n_parent = tl.count[k];
+int launch_upper(const TreeLayout &tl, const TreeView &tv, unsigned n_pairs, hipStream_t s, std::string *err,
+                 int first = 2, uint64_t n_level1 = 0) {
+    for (int k = first; k < tl.n_levels; ++k) {
+        const uint64_t n_child = k == 1 ? n_level1 : tl.count[k - 1], n_parent = tl.count[k];
         dim3 grid(query_grid(n_parent), n_pairs);
         hipLaunchKernelGGL(tree_up_kernel<Node>, grid, dim3(256), 0, s, tv, k - 1, n_child, n_parent);
         if (int rc = hip_fail(hipGetLastError(), "tree_up_kernel", err)) return rc;
@@ -522,8 +627,21 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes);
         if (p0 == 0) if (int rc = record(ev_build0, s, err)) return rc;
         if (n > 0) {
-            hipLaunchKernelGGL(fst_build_kernel, dim3(build_grid(tl.count[1]), np), dim3(256), 0, s, cols, n,
-                               tl.count[1], tv);
+            const BuildTuning bt = build_tuning();
+            const dim3 grid(build_grid(tl.count[1], bt.blocks), np);
+#ifdef PGT_TIMING_ONLY_BUILD  // tools/ablate_build.py: never defined in the product build
+            if (std::getenv("PGT_TUNE_BUILD_ABLATE"))
+                hipLaunchKernelGGL((fst_build_kernel<4, true, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            else
+#endif
+            if (bt.unroll == 8 && bt.nt)
+                hipLaunchKernelGGL((fst_build_kernel<8, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            else if (bt.unroll == 8)
+                hipLaunchKernelGGL((fst_build_kernel<8, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            else if (bt.nt)
+                hipLaunchKernelGGL((fst_build_kernel<4, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            else
+                hipLaunchKernelGGL((fst_build_kernel<4, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
         }
@@ -546,9 +664,10 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
     const TreeView tv = make_view(tl, tree, tl.bytes);
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s, g, n, tl.count[1], tv);
+        const uint64_t n_items = het_items(n);
+        hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
         if (int rc = hip_fail(hipGetLastError(), "het_build_kernel", err)) return rc;
-        if (int rc = launch_upper<NodeHet>(tl, tv, 1, s, err)) return rc;
+        if (int rc = launch_upper<NodeHet>(tl, tv, 1, s, err, 1, n_items * kHetChunk)) return rc;
     }
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0) {
@@ -579,6 +698,37 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
         hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
                            win, n_win, out, n, tot);
         if (int rc = hip_fail(hipGetLastError(), "query_kernel<dxy>", err)) return rc;
+    }
+    return record(ev_query1, s, err);
+}
+
+int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
+                   const int8_t *g1, const int8_t *g2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+                   pgt_dxy_row *dxy_out, pgt_dxy_total *tot, pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree,
+                   void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout td = tree_layout(PGT_STAT_DXY, n), th = tree_layout(PGT_STAT_HET, n);
+    char *base = static_cast<char *>(tree);
+    const TreeView tvd = make_view(td, base, td.bytes);
+    const TreeView tvh0 = make_view(th, base + td.bytes, th.bytes);
+    const TreeView tvh1 = make_view(th, base + td.bytes + th.bytes, th.bytes);
+    if (int rc = record(ev_build0, s, err)) return rc;
+    if (n > 0) {
+        const uint64_t n_items = het_items(n);
+        DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], n_items, tvd, {tvh0, tvh1}};
+        const uint64_t tiles = td.count[1] > n_items ? td.count[1] : n_items;
+        hipLaunchKernelGGL(dxy_het_build_kernel, dim3(build_grid(tiles), 3), dim3(256), 0, s, f);
+        if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
+        if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
+        if (int rc = launch_upper<NodeHet>(th, tvh0, 1, s, err, 1, n_items * kHetChunk)) return rc;
+        if (int rc = launch_upper<NodeHet>(th, tvh1, 1, s, err, 1, n_items * kHetChunk)) return rc;
+    }
+    if (int rc = record(ev_build1, s, err)) return rc;
+    if (n_win > 0 || tot) {
+        DxyHetQueryArgs q{DxyTraits::Args{p1, p2, n1, n2, minind}, {g1, g2}, tvd, {tvh0, tvh1}, dxy_out, tot,
+                          {het_out1, het_out2}};
+        hipLaunchKernelGGL(dxy_het_query_kernel, dim3(query_grid(n_win + 1), 3), dim3(256), 0, s, q, pos, win, n_win, n);
+        if (int rc = hip_fail(hipGetLastError(), "dxy_het_query_kernel", err)) return rc;
     }
     return record(ev_query1, s, err);
 }

@@ -230,6 +230,29 @@ class Context:
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tot, tree
 
+    def dxy_het_reduce_dev(self, pos, p1, p2, n1, n2, g1, g2, minind, win, tree=None, stream=None):
+        """BASELINE config 3: dxy + het(g1) + het(g2) over one pos column / window table, two launches."""
+        import torch
+        n = p1.numel()
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        dev = p1.device
+        if tree is None:
+            tree = torch.empty(self.tree_bytes(PGT_STAT_DXY, n) + 2 * self.tree_bytes(PGT_STAT_HET, n),
+                               dtype=torch.uint8, device=dev)
+        dxy_out = torch.empty(n_win * DXY_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        tot = torch.empty(DXY_TOTAL_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        h1 = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        h2 = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self._check(self._lib.pgt_dxy_het_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
+            self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
+            self._dev(g1, torch.int8, "g1"), self._dev(g2, torch.int8, "g2"), n, int(minind),
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(dxy_out, torch.uint8, "dxy_out"),
+            self._dev(tot, torch.uint8, "tot"), self._dev(h1, torch.uint8, "het_out1"),
+            self._dev(h2, torch.uint8, "het_out2"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
+            self._stream(stream)))
+        return dxy_out, tot, h1, h2, tree
+
     # ---- per-kernel timing ------------------------------------------------------------------
     def set_profiling(self, enabled: bool):
         self._check(self._lib.pgt_set_profiling(self._ctx, int(enabled)))

@@ -364,3 +364,51 @@ def test_full_size_properties(pgt, ctx):
     assert int(rt["n"].astype(np.int64).sum()) == n
     assert_close([rt["bsum"].sum()], [float(b.sum())], "cover bsum")
     assert_close([rt["asum"].sum()], [float(a.sum())], "cover asum")
+
+
+def test_fused_dxy_het_equals_separate_bitwise(pgt, ctx, oracle):
+    """BASELINE config 3 entry point: same bytes as the three separate reductions, and the oracle's
+    counts."""
+    import torch
+    rng = np.random.default_rng(31)
+    n = 900_001
+    chr_ids, pos = synth.chromosomes(rng, n, 5, equal=False)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    g1 = synth.het_column(rng, n).astype(np.int8)
+    g2 = synth.het_column(rng, n).astype(np.int8)
+    W, S, minind = 50_000, 10_000, 5
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(x).to(dev)
+    dxy_out, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(t(pos.view(np.int32)), t(p1), t(p2), t(n1), t(n2), t(g1), t(g2),
+                                                    minind, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    d_sep, tot_sep = ctx.dxy_reduce(pos, p1, p2, n1, n2, minind, win)
+    assert rows_from_device(dxy_out, DXY_ROW_DTYPE).tobytes() == d_sep.tobytes()
+    assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == np.array([tot_sep]).tobytes()
+    assert rows_from_device(h1, HET_ROW_DTYPE).tobytes() == ctx.het_reduce(pos, g1, win).tobytes()
+    assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == ctx.het_reduce(pos, g2, win).tobytes()
+    ref = oracle.het_scan(chr_ids, pos, g2.astype(np.int32), W, S)
+    assert np.array_equal(rows_from_device(h2, HET_ROW_DTYPE)["nonmissing"], ref["n"])
+
+
+def test_rccl_gather_single_rank(pgt, ctx):
+    """The bench's gather path on the RCCL backend (one rank is all a 1-GPU box allows): process
+    group init with the nccl backend, barrier, and gather_rows through torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    from popgenomicstools_amd.distributed import gather_rows
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", world_size=1, rank=0, device_id=dev)
+    try:
+        rows = torch.arange(40 * 7, dtype=torch.uint8, device=dev)
+        send = torch.zeros(40 * 7, dtype=torch.uint8, device=dev)
+        send.copy_(rows)
+        recv = [torch.empty_like(send)]
+        dist.gather(send, recv, dst=0)  # the collective gather_rows issues when world > 1
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(recv[0], rows)
+        assert torch.equal(gather_rows(rows, [7], 40, dst=0), rows)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Build-kernel time / HBM rate of the other BASELINE configs on one MI355X (markdown on stdout):
+config 2  fstWindow 10^8 sites              16 B/site
+config 3  dxyWindow + hetWindow 10^8 sites  26 B/site (fused entry point) and each tool alone
+config 5  fstWindow, 28 population pairs x 10^8 sites, one table, 448 B/site (all pairs on ONE GPU here)
+plus the host-buffer entry point (PCIe included) for the record."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import popgenomicstools_amd as pgt  # noqa: E402
+from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
+
+
+def timed(ctx, fn, reps=12):
+    ctx.set_profiling(True)
+    b, q = [], []
+    for r in range(reps + 2):
+        fn()
+        bm, qm = ctx.last_kernel_ms()
+        if r >= 2:
+            b.append(bm); q.append(qm)
+    ctx.set_profiling(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return float(np.median(b)), float(np.median(q)), (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    n, chroms, W, S = 100_000_000, 20, 50_000, 10_000
+    ctx = pgt.Context(0)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    pos, a, b, run_len = bench.synth_columns(n, chroms, 12345, dev)
+    win = windows_to_device(pgt.build_windows_sites(run_len, W, S), dev)
+    print("| config | bytes/site | build ms | GB/s | % of 8 TB/s | query ms | whole step ms | sites/s |")
+    print("|---|---|---|---|---|---|---|---|")
+
+    def row(name, bps, res):
+        bm, qm, step = res
+        print(f"| {name} | {bps} | {bm:.4f} | {bps * n / bm / 1e6:.0f} | {bps * n / bm / 1e6 / 80:.1f} | {qm:.4f} | {step:.4f} | {n / step * 1e3:.3e} |")
+
+    from popgenomicstools_amd._lib import PGT_STAT_DXY, PGT_STAT_FST, PGT_STAT_HET
+    tree = torch.empty(28 * ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)  # reused by every config
+    out = torch.empty(28 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
+    row("2: fstWindow 1e8", 16, timed(ctx, lambda: ctx.fst_reduce_dev(pos, a, b, win, out=out, tree=tree)))
+    p1 = torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 1e6) / 1e6
+    p2 = torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 1e6) / 1e6
+    n1 = torch.randint(0, 21, (n,), generator=gen, device=dev, dtype=torch.int32)
+    n2 = torch.randint(0, 21, (n,), generator=gen, device=dev, dtype=torch.int32)
+    g1 = (torch.randint(0, 20, (n,), generator=gen, device=dev, dtype=torch.int32) % 4 - 1).to(torch.int8)
+    g2 = (torch.randint(0, 20, (n,), generator=gen, device=dev, dtype=torch.int32) % 4 - 1).to(torch.int8)
+    row("3a: dxyWindow alone 1e8", 24, timed(ctx, lambda: ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, 5, win, out=out, tree=tree)))
+    row("3b: hetWindow alone 1e8", 1, timed(ctx, lambda: ctx.het_reduce_dev(pos, g1, win, out=out, tree=tree)))
+    row("3: dxy + het x2 fused 1e8", 26, timed(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)))
+    del p1, p2, n1, n2, g1, g2
+    n_pairs = 28
+    al = [a] + [a.roll(1000 * (k + 1)) for k in range(n_pairs - 1)]
+    bl = [b] + [b.roll(1000 * (k + 1)) for k in range(n_pairs - 1)]
+    row("5: fstWindow 28 pairs x 1e8 (one GPU)", 448, timed(ctx, lambda: ctx.fst_reduce_pairs_dev(pos, al, bl, win, out=out, tree=tree), reps=6))
+    del al, bl
+    # host-buffer entry point: H2D of 20 B/site + kernels + D2H, synchronous
+    m = 50_000_000
+    hp, ha, hb = pos[:m].cpu().numpy().view(np.uint32), a[:m].cpu().numpy(), b[:m].cpu().numpy()
+    hw = pgt.build_windows_sites(np.full(10, m // 10, dtype=np.uint64), W, S)
+    ctx.fst_reduce(hp, ha, hb, hw)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.fst_reduce(hp, ha, hb, hw)
+    dt = (time.perf_counter() - t0) / 3
+    print(f"\nhost-buffer pgt_fst_reduce (pageable host memory, PCIe included), {m:.0e} sites: {dt * 1e3:.1f} ms = {m / dt:.3e} sites/s = {20 * m / dt / 1e9:.1f} GB/s over the link")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
