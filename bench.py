@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 import popgenomicstools_amd as pgt  # noqa: E402
 from popgenomicstools_amd._lib import FST_ROW_DTYPE, PGT_STAT_FST  # noqa: E402
-from popgenomicstools_amd.distributed import gather_rows  # noqa: E402
+from popgenomicstools_amd.distributed import RowGatherer  # noqa: E402
 from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
@@ -137,14 +137,16 @@ def main():
     win = pgt.build_windows_sites(run_len, W, S)  # host, O(#windows)
     win_d = windows_to_device(win, dev)
     ctx = pgt.Context(local_rank)
+    ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
     tree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
     out = torch.empty(win.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     counts = [win.size] * world  # every rank has the same geometry
+    gather = RowGatherer(counts, FST_ROW_DTYPE.itemsize, dev, dst=0) if world > 1 else None
 
     def step():
         ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
-        if world > 1:
-            return gather_rows(out, counts, FST_ROW_DTYPE.itemsize, dst=0)
+        if gather is not None:
+            return gather(out)  # one RCCL gather of 40 B/window to rank 0
         return out
 
     def fence():

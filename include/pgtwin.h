@@ -150,6 +150,13 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
                              const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
                              size_t tree_bytes, void *stream);
 
+/* ---- performance hint ------------------------------------------------------------------- */
+/* Longest window (in sites) the following *_dev calls will be asked for; 0 (the default) = unknown.
+ * Tree levels whose nodes are larger than this are not built (a query never touches them).  The
+ * hint only affects speed: a longer window is still answered correctly from the levels that
+ * exist.  The host-buffer entry points derive it from the table themselves. */
+int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
+
 /* ---- per-kernel timing (HIP events on the launch stream; for bench.py's roofline) ------- */
 /* When enabled, the *_dev entry points bracket the tree-build kernel and the window-query
  * kernel with HIP events; pgt_last_kernel_ms synchronises on them and returns both. */

@@ -64,7 +64,7 @@ def build_hosts(force: bool = False) -> list[str]:
         exe = os.path.join(BIN, tool)
         if force or _newer(exe, [src] + common):
             _run([_hipcc(), "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, src,
-                  "-o", exe, "-L" + PKG, "-lpgtwin", "-lz", "-Wl,-rpath,$ORIGIN/.."])
+                  "-o", exe, "-L" + PKG, "-lpgtwin", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/.."])
         out.append(exe)
     return out
 

@@ -15,6 +15,7 @@ struct pgt_ctx {
     std::string error;
     bool profiling = false;
     bool have_timing = false;
+    uint64_t max_window = 0;  // pgt_set_max_window hint (0 = unknown)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // build start, build end, query end
 };
 
@@ -47,6 +48,19 @@ struct DevBuf {
         if (!bytes) return PGT_OK;
         return hip_check(ctx, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), what);
     }
+};
+
+// RAII: the host-buffer entry points know the table, so they set the max-window hint themselves
+struct HintScope {
+    pgt_ctx *ctx;
+    uint64_t saved;
+    HintScope(pgt_ctx *c, const pgt_win *win, uint64_t n_win) : ctx(c), saved(c->max_window) {
+        uint64_t m = 1;
+        for (uint64_t i = 0; i < n_win; ++i)
+            if (win[i].hi >= win[i].lo && win[i].hi - win[i].lo > m) m = win[i].hi - win[i].lo;
+        c->max_window = m;
+    }
+    ~HintScope() { ctx->max_window = saved; }
 };
 
 int check_windows_host(pgt_ctx *ctx, const pgt_win *win, uint64_t n_win, uint64_t n, bool need_coords_or_sites) {
@@ -149,6 +163,12 @@ int pgt_set_profiling(pgt_ctx *ctx, int enabled) {
     return PGT_OK;
 }
 
+int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites) {
+    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+    ctx->max_window = max_window_sites;
+    return PGT_OK;
+}
+
 int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms) {
     if (!ctx || !build_ms || !query_ms) return ctx_fail(ctx, PGT_EARG, "pgt_last_kernel_ms: NULL argument");
     if (!ctx->have_timing) return ctx_fail(ctx, PGT_EARG, "pgt_last_kernel_ms: no profiled call yet");
@@ -171,7 +191,7 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
     if (!aligned16(tree) || tree_bytes < (size_t)n_pairs * pgt_tree_bytes(PGT_STAT_FST, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
-    return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error);
+    return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
 }
 
 int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
@@ -190,7 +210,7 @@ int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_HET, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
-    return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error);
+    return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
 }
 
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
@@ -206,7 +226,7 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_dxy(pos, p1, p2, n1, n2, n, minind, win, n_win, out, tot, tree, stream, e.b0, e.b1, e.q1,
-                      &ctx->error);
+                      &ctx->error, ctx->max_window);
 }
 
 int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
@@ -224,7 +244,7 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_dxy_het(pos, p1, p2, n1, n2, g1, g2, n, minind, win, n_win, dxy_out, tot, het_out1, het_out2, tree,
-                          stream, e.b0, e.b1, e.q1, &ctx->error);
+                          stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
 }
 
 /* ---------------- host-buffer entry points ---------------- */
@@ -234,6 +254,7 @@ int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const dou
     if (int rc = use_device(ctx)) return rc;
     if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
     DevBuf dpos, da, db, dwin, dout, dtree;
     if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
     if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
@@ -256,6 +277,7 @@ int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t 
     if (int rc = use_device(ctx)) return rc;
     if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
     DevBuf dpos, dg, dwin, dout, dtree;
     if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
     if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
@@ -279,6 +301,7 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
     if ((n && (!pos || !p1 || !p2 || !n1 || !n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
     DevBuf dpos, d1, d2, dn1, dn2, dwin, dout, dtot, dtree;
     if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
     if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;

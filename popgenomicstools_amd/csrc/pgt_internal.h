@@ -60,23 +60,37 @@ inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
     return t;
 }
 
+// Levels worth building when no window is longer than max_window sites (0 = unknown: all).
+// Level k (k >= 3) has nodes of leaf*64^(k-1) sites; a window can only contain such a node if it
+// is at least that long.  Levels 1 and 2 always exist (the build kernels write them).
+inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
+    if (max_window == 0) return t.n_levels;
+    int k = 2;
+    uint64_t node = (uint64_t)leaf_sites(stat) * kRadix * kRadix;  // level-3 node
+    while (k < t.n_levels && node <= max_window) {
+        ++k;
+        node *= kRadix;
+    }
+    return k;
+}
+
 // ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
-               void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err);
+               void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
                pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
-               void *ev_query1, std::string *err);
+               void *ev_query1, std::string *err, uint64_t max_window);
 int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, void *stream, void *ev_build0,
-               void *ev_build1, void *ev_query1, std::string *err);
+               void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 
 int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                    const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
                    const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
                    pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, void *stream,
-                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err);
+                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 
 // thread-local message for the ctx-less entry points
 void set_global_error(const std::string &msg);

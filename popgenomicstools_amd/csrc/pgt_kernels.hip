@@ -584,11 +584,12 @@ inline unsigned query_grid(uint64_t n_items) {
 
 inline uint64_t het_items(uint64_t n) { return (n + (uint64_t)kLeafI8 * kHetChunk - 1) / ((uint64_t)kLeafI8 * kHetChunk); }
 
-TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride) {
+// levels = how many tree levels are built and may be used by queries (useful_levels()).
+TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride, int levels) {
     TreeView tv{};
     tv.base = static_cast<char *>(tree);
     tv.pair_stride = pair_stride;
-    tv.n_levels = tl.n_levels;
+    tv.n_levels = levels;
     for (int k = 0; k < tl.n_levels; ++k) tv.off[k] = tl.offset[k];
     return tv;
 }
@@ -599,7 +600,7 @@ TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride) {
 template <class Node>
 int launch_upper(const TreeLayout &tl, const TreeView &tv, unsigned n_pairs, hipStream_t s, std::string *err,
                  int first = 2, uint64_t n_level1 = 0) {
-    for (int k = first; k < tl.n_levels; ++k) {
+    for (int k = first; k < tv.n_levels; ++k) {
         const uint64_t n_child = k == 1 ? n_level1 : tl.count[k - 1], n_parent = tl.count[k];
         dim3 grid(query_grid(n_parent), n_pairs);
         hipLaunchKernelGGL(tree_up_kernel<Node>, grid, dim3(256), 0, s, tv, k - 1, n_child, n_parent);
@@ -617,14 +618,15 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
-               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
+    const int levels = useful_levels(tl, PGT_STAT_FST, max_window);
     for (uint32_t p0 = 0; p0 < n_pairs; p0 += kMaxPairs) {
         const uint32_t np = n_pairs - p0 < (uint32_t)kMaxPairs ? n_pairs - p0 : (uint32_t)kMaxPairs;
         PairCols cols{};
         for (uint32_t p = 0; p < np; ++p) { cols.a[p] = a[p0 + p]; cols.b[p] = b[p0 + p]; }
-        const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes);
+        const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes, levels);
         if (p0 == 0) if (int rc = record(ev_build0, s, err)) return rc;
         if (n > 0) {
             const BuildTuning bt = build_tuning();
@@ -658,10 +660,10 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
 
 int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
                pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1,
-               std::string *err) {
+               std::string *err, uint64_t max_window) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_HET, n);
-    const TreeView tv = make_view(tl, tree, tl.bytes);
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_HET, max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);
@@ -681,10 +683,12 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
 
 int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
                uint64_t n, int minind, const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
-               void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+               void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err,
+               uint64_t max_window) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_DXY, n);
-    const TreeView tv = make_view(tl, tree, tl.bytes);
+    // the genome-wide total is a query over [0,n): it wants every level
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s, p1, p2, n1, n2, n,
@@ -705,13 +709,15 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
 int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
                    const int8_t *g1, const int8_t *g2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                    pgt_dxy_row *dxy_out, pgt_dxy_total *tot, pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree,
-                   void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err) {
+                   void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err,
+                   uint64_t max_window) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout td = tree_layout(PGT_STAT_DXY, n), th = tree_layout(PGT_STAT_HET, n);
     char *base = static_cast<char *>(tree);
-    const TreeView tvd = make_view(td, base, td.bytes);
-    const TreeView tvh0 = make_view(th, base + td.bytes, th.bytes);
-    const TreeView tvh1 = make_view(th, base + td.bytes + th.bytes, th.bytes);
+    const int lh = useful_levels(th, PGT_STAT_HET, max_window);
+    const TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, tot ? 0 : max_window));
+    const TreeView tvh0 = make_view(th, base + td.bytes, th.bytes, lh);
+    const TreeView tvh1 = make_view(th, base + td.bytes + th.bytes, th.bytes, lh);
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);

@@ -25,6 +25,37 @@ def shard_windows(win: np.ndarray, rank: int, world: int):
     return s, local, shards
 
 
+class RowGatherer:
+    """gather_rows with its buffers allocated once (the bench's per-step path): when every rank has
+    the same number of windows the local row tensor is sent as it is, no staging copy."""
+
+    def __init__(self, counts, row_bytes: int, device, dst: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.counts = [int(c) for c in counts]
+        self.row_bytes, self.dst, self.group = row_bytes, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.width = max(self.counts) * row_bytes
+        self.uniform = len(set(self.counts)) == 1
+        self.send = None if self.uniform else torch.zeros(self.width, dtype=torch.uint8, device=device)
+        self.recv = ([torch.empty(self.width, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == dst else None)
+
+    def __call__(self, local_rows):
+        """Returns on dst the list of per-rank row tensors (views, valid until the next call)."""
+        if self.uniform:
+            send = local_rows
+        else:
+            send = self.send
+            send[: local_rows.numel()].copy_(local_rows)
+        self.dist.gather(send, self.recv, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        return [self.recv[r][: self.counts[r] * self.row_bytes] for r in range(self.world)]
+
+
 def gather_rows(local_rows, counts, row_bytes: int, dst: int = 0, group=None):
     """Gather per-rank packed row tensors (uint8, counts[r]*row_bytes bytes on rank r) to `dst`.
 

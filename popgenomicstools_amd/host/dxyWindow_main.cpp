@@ -40,38 +40,34 @@ static void help(unsigned W, unsigned S, int minind, int fixedsite, int skip_mis
 
 struct Maf {
     Runs runs;
-    std::vector<uint32_t> pos;
-    std::vector<double> freq;
-    std::vector<int32_t> nind;
+    Column<uint32_t> pos;
+    Column<double> freq;
+    Column<int32_t> nind;
+    size_t n = 0;
+    void alloc(size_t rows) { pos.alloc(rows); freq.alloc(rows); nind.alloc(rows); }
+    // chr pos major minor ref freq nind — only chr, pos, freq, nind are used (dxyWindow.cpp:141-153)
+    bool parse_line(Cursor &c, size_t i, Runs &r) {
+        const Tok chr = c.token();
+        long long k;
+        bool ok = to_u32(c.token(), pos[i]);
+        c.token(); c.token(); c.token();  // major minor ref
+        ok = ok && to_f64(c.token(), freq[i]) && to_i64(c.token(), k);
+        // a frequency outside [0,1] would make dxy negative, which the reference neither counts nor
+        // skips (dxyWindow.cpp:180-185): refuse it
+        if (!ok || !(freq[i] >= 0.0 && freq[i] <= 1.0)) return false;
+        nind[i] = (int32_t)std::max<long long>(std::min<long long>(k, INT32_MAX), INT32_MIN);
+        r.add(chr.first, chr.second);
+        return true;
+    }
 };
 
-// chr pos major minor ref freq nind — only chr, pos, freq, nind are used (dxyWindow.cpp:141-153)
 static void read_maf(const char *path, const char *which, Maf &m) {
-    std::string text;
-    if (!slurp(path, text)) die(std::string("Unable to open ") + which + " MAF file: " + path);
-    Cursor c{text.data(), text.data() + text.size()};
-    c.next_line();  // header (dxyWindow.cpp:284)
-    size_t line = 1;
-    while (c.p < c.end) {
-        ++line;
-        c.skip_blank();
-        if (c.at_eol()) break;  // dxyWindow.cpp:313
-        auto chr = c.token();
-        uint32_t p;
-        double f;
-        long long k;
-        bool ok = to_u32(c.token(), p);
-        c.token(); c.token(); c.token();  // major minor ref
-        ok = ok && to_f64(c.token(), f) && to_i64(c.token(), k);
-        if (!ok) die(std::string("dxyWindow: cannot parse MAF line ") + std::to_string(line) + " of " + path);
-        if (!(f >= 0.0 && f <= 1.0))
-            die(std::string("dxyWindow: allele frequency outside [0,1] on line ") + std::to_string(line) + " of " + path);
-        m.runs.add(chr.first, chr.second);
-        m.pos.push_back(p);
-        m.freq.push_back(f);
-        m.nind.push_back((int32_t)std::max<long long>(std::min<long long>(k, INT32_MAX), INT32_MIN));
-        c.next_line();
-    }
+    Text text;
+    if (!text.open(path)) die(std::string("Unable to open ") + which + " MAF file: " + path);
+    Cursor hdr{text.begin(), text.end()};
+    hdr.next_line();  // header (dxyWindow.cpp:284)
+    m.n = parse_table(hdr.p, text.end(), m, m.runs,
+                      "dxyWindow: cannot parse MAF line (chr pos major minor ref freq nind, freq in [0,1])", path, 2);
 }
 
 int main(int argc, char **argv) {
@@ -102,9 +98,9 @@ int main(int argc, char **argv) {
 
     std::map<std::string, uint32_t> chrsize;  // dxyWindow.cpp:155-170
     if (!fixedsite) {
-        std::string text;
-        if (!slurp(sizefile, text)) die(std::string("Unable to open sizefile: ") + sizefile);
-        Cursor c{text.data(), text.data() + text.size()};
+        Text text;
+        if (!text.open(sizefile)) die(std::string("Unable to open sizefile: ") + sizefile);
+        Cursor c{text.begin(), text.end()};
         while (c.p < c.end) {
             auto name = c.token();
             uint32_t len = 0;
@@ -115,10 +111,15 @@ int main(int argc, char **argv) {
         }
     }
 
+    PhaseTimer timer;
     Maf m1, m2;
-    read_maf(argv[argc - 2], "Pop1", m1);
-    read_maf(argv[argc - 1], "Pop2", m2);
-    if (m1.pos.empty() || m2.pos.empty()) die("dxyWindow: a MAF file holds no sites");
+    {   // the two files are independent: parse them side by side
+        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1); });
+        read_maf(argv[argc - 1], "Pop2", m2);
+        t1.join();
+    }
+    timer.lap("parse");
+    if (m1.n == 0 || m2.n == 0) die("dxyWindow: a MAF file holds no sites");
     if (m1.runs.name[0] != m2.runs.name[0]) die("Chromosomes in MAF files differ");  // dxyWindow.cpp:295-298
 
     // intersection by (run, position)
@@ -174,12 +175,14 @@ int main(int argc, char **argv) {
         }
     }
 
+    timer.lap("sync + table");
     pgt_ctx *ctx = open_or_die();
     std::vector<pgt_dxy_row> rows(win.size());
     pgt_dxy_total tot{};
     check(pgt_dxy_reduce(ctx, pos.data(), p1.data(), p2.data(), n1.data(), n2.data(), pos.size(), minind, win.data(),
                          win.size(), rows.data(), &tot), ctx);
     pgt_close(ctx);
+    timer.lap("gpu reduce");
 
     static char obuf[1 << 20];
     std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);

@@ -22,31 +22,26 @@ int main(int argc, char **argv) {
         usage(W, S);
         return 0;
     }
-    std::string text;
-    if (!slurp(argv[1], text)) die(std::string("Unable to open Fst variance components file ") + argv[1]);
+    PhaseTimer timer;
+    Text text;
+    if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
     parse_window_args(argc, argv, W, S);
 
+    // chr pos a b  (fstWindow.cpp:130,141), parsed in parallel chunks straight into the columns
+    struct Table {
+        Column<uint32_t> pos;
+        Column<double> a, b;
+        void alloc(size_t rows) { pos.alloc(rows); a.alloc(rows); b.alloc(rows); }
+        bool parse_line(Cursor &c, size_t i, Runs &runs) {
+            const Tok chr = c.token();
+            if (!to_u32(c.token(), pos[i]) || !to_f64(c.token(), a[i]) || !to_f64(c.token(), b[i])) return false;
+            runs.add(chr.first, chr.second);
+            return true;
+        }
+    } tab;
     Runs runs;
-    std::vector<uint32_t> pos;
-    std::vector<double> a, b;
-    const size_t guess = text.size() / 24 + 16;
-    pos.reserve(guess); a.reserve(guess); b.reserve(guess);
-    Cursor c{text.data(), text.data() + text.size()};
-    size_t line = 0;
-    while (c.p < c.end) {
-        ++line;
-        c.skip_blank();
-        if (c.at_eol()) break;  // the reference loop ends at the first empty line (fstWindow.cpp:125)
-        auto chr = c.token();
-        uint32_t p;
-        double x, y;
-        if (!to_u32(c.token(), p) || !to_f64(c.token(), x) || !to_f64(c.token(), y))
-            die("fstWindow: cannot parse 'chr pos a b' on line " + std::to_string(line) + " of " + argv[1]);
-        runs.add(chr.first, chr.second);
-        pos.push_back(p); a.push_back(x); b.push_back(y);
-        c.next_line();
-    }
-    std::string().swap(text);
+    const size_t n = parse_table(text.begin(), text.end(), tab, runs, "fstWindow: cannot parse 'chr pos a b'", argv[1], 1);
+    timer.lap("parse");
 
     size_t n_win = 0;
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
@@ -56,13 +51,17 @@ int main(int argc, char **argv) {
 
     pgt_ctx *ctx = open_or_die();
     std::vector<pgt_fst_row> rows(n_win);
-    check(pgt_fst_reduce(ctx, pos.data(), a.data(), b.data(), pos.size(), win.data(), n_win, rows.data()), ctx);
+    timer.lap("window table");
+    check(pgt_fst_reduce(ctx, tab.pos.data(), tab.a.data(), tab.b.data(), n, win.data(), n_win, rows.data()), ctx);
     pgt_close(ctx);
+    timer.lap("gpu reduce");
 
     static char obuf[1 << 20];
     std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
     for (size_t i = 0; i < n_win; ++i)  // %g == std::ostream default formatting (fstWindow.cpp:88)
         std::printf("%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start, rows[i].end,
                     rows[i].mid, rows[i].fst, rows[i].n);
+    std::fflush(stdout);
+    timer.lap("print");
     return 0;
 }

@@ -24,33 +24,29 @@ int main(int argc, char **argv) {
         usage(W, S);
         return 0;
     }
-    std::string text;
-    if (!slurp(argv[1], text)) die(std::string("Unable to open genotypes file ") + argv[1]);
+    PhaseTimer timer;
+    Text text;
+    if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
     parse_window_args(argc, argv, W, S);
 
+    // chr pos genotype  (hetWindow.cpp:128,139), parsed in parallel chunks straight into the columns
+    struct Table {
+        Column<uint32_t> pos;
+        Column<int8_t> g;
+        void alloc(size_t rows) { pos.alloc(rows); g.alloc(rows); }
+        bool parse_line(Cursor &c, size_t i, Runs &runs) {
+            const Tok chr = c.token();
+            long long v;
+            if (!to_u32(c.token(), pos[i]) || !to_i64(c.token(), v)) return false;
+            // only `>= 0` and `== 1` are ever tested (hetWindow.cpp:78-80): clamping to int8 keeps both
+            g[i] = (int8_t)std::clamp<long long>(v, -128, 127);
+            runs.add(chr.first, chr.second);
+            return true;
+        }
+    } tab;
     Runs runs;
-    std::vector<uint32_t> pos;
-    std::vector<int8_t> g;
-    const size_t guess = text.size() / 12 + 16;
-    pos.reserve(guess); g.reserve(guess);
-    Cursor c{text.data(), text.data() + text.size()};
-    size_t line = 0;
-    while (c.p < c.end) {
-        ++line;
-        c.skip_blank();
-        if (c.at_eol()) break;  // hetWindow.cpp:123
-        auto chr = c.token();
-        uint32_t p;
-        long long v;
-        if (!to_u32(c.token(), p) || !to_i64(c.token(), v))
-            die("hetWindow: cannot parse 'chr pos genotype' on line " + std::to_string(line) + " of " + argv[1]);
-        runs.add(chr.first, chr.second);
-        pos.push_back(p);
-        // only `>= 0` and `== 1` are ever tested (hetWindow.cpp:78-80): clamping to int8 keeps both
-        g.push_back((int8_t)std::clamp<long long>(v, -128, 127));
-        c.next_line();
-    }
-    std::string().swap(text);
+    const size_t n = parse_table(text.begin(), text.end(), tab, runs, "hetWindow: cannot parse 'chr pos genotype'", argv[1], 1);
+    timer.lap("parse");
 
     size_t n_win = 0;
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
@@ -60,8 +56,10 @@ int main(int argc, char **argv) {
 
     pgt_ctx *ctx = open_or_die();
     std::vector<pgt_het_row> rows(n_win);
-    check(pgt_het_reduce(ctx, pos.data(), g.data(), pos.size(), win.data(), n_win, rows.data()), ctx);
+    timer.lap("window table");
+    check(pgt_het_reduce(ctx, tab.pos.data(), tab.g.data(), n, win.data(), n_win, rows.data()), ctx);
     pgt_close(ctx);
+    timer.lap("gpu reduce");
 
     static char obuf[1 << 20];
     std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);

@@ -253,6 +253,10 @@ class Context:
             self._stream(stream)))
         return dxy_out, tot, h1, h2, tree
 
+    def set_max_window(self, sites: int):
+        """Performance hint for the *_dev calls: no window is longer than `sites` (0 = unknown)."""
+        self._check(self._lib.pgt_set_max_window(self._ctx, int(sites)))
+
     # ---- per-kernel timing ------------------------------------------------------------------
     def set_profiling(self, enabled: bool):
         self._check(self._lib.pgt_set_profiling(self._ctx, int(enabled)))

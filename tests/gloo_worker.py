@@ -16,7 +16,7 @@ import oracle_bind  # noqa: E402
 import synth  # noqa: E402
 from popgenomicstools_amd import build_windows_sites, run_lengths  # noqa: E402
 from popgenomicstools_amd._lib import FST_ROW_DTYPE  # noqa: E402
-from popgenomicstools_amd.distributed import gather_rows, shard_windows  # noqa: E402
+from popgenomicstools_amd.distributed import RowGatherer, gather_rows, shard_windows  # noqa: E402
 
 
 def cpu_reduce(pos, a, b, win):
@@ -46,7 +46,9 @@ def main():
     counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64)
     packed = torch.from_numpy(rows.view(np.uint8).copy())
     allrows = gather_rows(packed, counts, FST_ROW_DTYPE.itemsize, dst=0)
+    parts = RowGatherer(counts, FST_ROW_DTYPE.itemsize, torch.device("cpu"), dst=0)(packed)  # the bench's form
     if rank == 0:
+        assert torch.equal(torch.cat(parts), allrows)
         got = np.frombuffer(allrows.numpy().tobytes(), dtype=FST_ROW_DTYPE)
         ref = oracle_bind.load().fst_scan(chr_ids, pos, a, b, W, S)
         assert got.size == ref.size == win.size

@@ -412,3 +412,26 @@ def test_rccl_gather_single_rank(pgt, ctx):
         assert torch.equal(gather_rows(rows, [7], 40, dst=0), rows)
     finally:
         dist.destroy_process_group()
+
+
+def test_max_window_hint_only_changes_speed(pgt, ctx):
+    """pgt_set_max_window: with the exact bound the rows are the same bytes (the skipped levels were
+    never touched); with a bound that is too small the answers are still right (1e-9)."""
+    import torch
+    rng = np.random.default_rng(41)
+    n = 3_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 2)
+    a, b = synth.fst_columns(rng, n)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 1_200_000, 400_000)  # windows contain level-3 nodes
+    base = _device_fst(ctx, pos, a, b, win)
+    try:
+        ctx.set_max_window(1_200_000)
+        assert _device_fst(ctx, pos, a, b, win).tobytes() == base.tobytes()
+        ctx.set_max_window(1000)  # wrong on purpose
+        low = _device_fst(ctx, pos, a, b, win)
+    finally:
+        ctx.set_max_window(0)
+    for f in ("start", "end", "mid", "n"):
+        assert np.array_equal(low[f], base[f])
+    assert_close(low["fst"], base["fst"], "fst under a too-small hint")
+    assert_close(low["asum"], base["asum"], "asum under a too-small hint")

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end wall time of the retained hosts vs the unmodified reference binaries on the same text
+input (parse + window scan + TSV), on this box.  Markdown on stdout."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_bind  # noqa: E402
+import synth  # noqa: E402
+
+BIN = os.path.join(ROOT, "popgenomicstools_amd", "bin")
+
+
+def wall(cmd, env=None):
+    t = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, env=env)
+    return time.perf_counter() - t, r
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+    orc = oracle_bind.load()
+    rng = np.random.default_rng(5)
+    chr_ids, pos = synth.chromosomes(rng, n, 20)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n)
+    d = tempfile.mkdtemp(prefix="pgt_e2e_")
+    f_fst, f_het = os.path.join(d, "fst.txt"), os.path.join(d, "het.txt")
+    orc.write_fst_text(f_fst, chr_ids, pos, a, b)
+    orc.write_het_text(f_het, chr_ids, pos, g)
+    print(f"{n:.0e} sites, W=50000 S=10000, host has {os.cpu_count()} logical cores\n")
+    print("| tool | reference (1 thread) s | this host s | speed-up | rows | TSV identical | host phases |")
+    print("|---|---|---|---|---|---|---|")
+    for tool, path in (("fstWindow", f_fst), ("hetWindow", f_het)):
+        env = dict(os.environ, PGT_HOST_TIMING="1")
+        wall([os.path.join(BIN, tool), path, "50000", "10000"], env)  # warm the page cache / GPU runtime
+        t_new, r_new = wall([os.path.join(BIN, tool), path, "50000", "10000"], env)
+        ref = oracle_bind.ref_binary(tool)
+        if ref:
+            t_ref, r_ref = wall([ref, path, "50000", "10000"])
+            same = r_ref.stdout == r_new.stdout
+            t_ref_s, sp = f"{t_ref:.2f}", f"{t_ref / t_new:.1f}x"
+        else:
+            same, t_ref_s, sp = "n/a", "n/a", "n/a"
+        phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
+        print(f"| {tool} | {t_ref_s} | {t_new:.2f} | {sp} | {len(r_new.stdout.splitlines())} | {same} | {phases} |")
+    for p in (f_fst, f_het):
+        os.unlink(p)
+    os.rmdir(d)
+
+
+if __name__ == "__main__":
+    main()
