@@ -47,8 +47,9 @@ def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
     deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(ROOT, "include", "pgtwin.h")]
     if force or _newer(LIB, deps):
+        extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPGT_TUNING_BUILD for tools/tune_build.py
         _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + srcs)
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + extra + srcs)
     return LIB
 
 

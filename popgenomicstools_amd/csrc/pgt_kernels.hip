@@ -550,8 +550,9 @@ inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     return PGT_EDEVICE;
 }
 
-// Launch geometry of the build kernels.  Defaults were chosen by interleaved A/B runs on MI355X
-// (profiles/r01/tune_build.md); the PGT_TUNE_* environment variables exist for that experiment only.
+// Launch geometry of the build kernels: 2048 workgroups (8 per CU), 4 leaf tiles per loop iteration
+// (8 x 16-byte loads in flight per lane), non-temporal loads — chosen by interleaved A/B runs on
+// MI355X (profiles/r01/tune_build.md).  The alternatives are only compiled with -DPGT_TUNING_BUILD.
 struct BuildTuning {
     unsigned blocks;  // workgroup cap; waves grid-stride over level-2 tiles beyond it (0 = no cap)
     int unroll;       // leaf tiles per loop iteration: 2*unroll 16-byte loads in flight per lane
@@ -559,9 +560,11 @@ struct BuildTuning {
 };
 inline BuildTuning build_tuning() {
     BuildTuning t{2048u, 4, true};
+#ifdef PGT_TUNING_BUILD
     if (const char *e = std::getenv("PGT_TUNE_BUILD_BLOCKS")) t.blocks = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("PGT_TUNE_BUILD_UNROLL")) t.unroll = std::atoi(e);
     if (const char *e = std::getenv("PGT_TUNE_BUILD_NT")) t.nt = std::atoi(e) != 0;
+#endif
     return t;
 }
 
@@ -631,19 +634,18 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         if (n > 0) {
             const BuildTuning bt = build_tuning();
             const dim3 grid(build_grid(tl.count[1], bt.blocks), np);
-#ifdef PGT_TIMING_ONLY_BUILD  // tools/ablate_build.py: never defined in the product build
+#ifdef PGT_TUNING_BUILD  // tools/tune_build.py, tools/ablate_build.py: never defined in the product build
             if (std::getenv("PGT_TUNE_BUILD_ABLATE"))
                 hipLaunchKernelGGL((fst_build_kernel<4, true, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else
-#endif
-            if (bt.unroll == 8 && bt.nt)
+            else if (bt.unroll == 8 && bt.nt)
                 hipLaunchKernelGGL((fst_build_kernel<8, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
             else if (bt.unroll == 8)
                 hipLaunchKernelGGL((fst_build_kernel<8, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else if (bt.nt)
-                hipLaunchKernelGGL((fst_build_kernel<4, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else
+            else if (!bt.nt)
                 hipLaunchKernelGGL((fst_build_kernel<4, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            else
+#endif
+                hipLaunchKernelGGL((fst_build_kernel<4, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
         }

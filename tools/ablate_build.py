@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing-only ablation: fst_build_kernel with the cross-lane butterfly removed (results wrong,
 loads identical) vs the real kernel, interleaved in one process.  Needs a library built with
--DPGT_TIMING_ONLY_BUILD (the product build does not contain the ablated kernel)."""
+-DPGT_TUNING_BUILD (the product build does not contain the ablated kernel)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

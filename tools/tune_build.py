@@ -4,6 +4,8 @@
 Variants are selected through the PGT_TUNE_BUILD_* environment variables that csrc/pgt_kernels.hip
 reads at launch time.  Prints median / min kernel time (HIP events around the build pass) per
 variant and size, as markdown.   usage: python tools/tune_build.py [rounds]
+Needs libpgtwin.so built with -DPGT_TUNING_BUILD (PGT_EXTRA_HIPCC_FLAGS=-DPGT_TUNING_BUILD python -m
+popgenomicstools_amd.build --force); the product build carries only the chosen variant.
 """
 import itertools
 import os
