@@ -184,13 +184,13 @@ int main(int argc, char **argv) {
     pgt_close(ctx);
     timer.lap("gpu reduce");
 
-    static char obuf[1 << 20];
-    std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
-    for (size_t i = 0; i < win.size(); ++i)
-        if (rows[i].neff > 0 || !skip_missing)  // dxyWindow.cpp:189-191
-            std::printf("%s\t%u\t%u\t%g\t%u\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start, rows[i].end,
-                        rows[i].sum, rows[i].neff, rows[i].nskip);
-    std::fflush(stdout);
+    // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)
+    write_rows(win.size(), longest_name(runs) + 80, [&](size_t i, char *o) -> size_t {
+        if (!(rows[i].neff > 0 || !skip_missing)) return 0;
+        return (size_t)std::sprintf(o, "%s\t%u\t%u\t%g\t%u\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
+                                    rows[i].end, rows[i].sum, rows[i].neff, rows[i].nskip);
+    });
+    timer.lap("print");
     // genome-wide line: stdout for the global run, stderr beside windows (dxyWindow.cpp:429-433)
     std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff,
                  (unsigned long long)tot.nskip);

@@ -61,10 +61,11 @@ int main(int argc, char **argv) {
     pgt_close(ctx);
     timer.lap("gpu reduce");
 
-    static char obuf[1 << 20];
-    std::setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
-    for (size_t i = 0; i < n_win; ++i)
-        std::printf("%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start, rows[i].end,
-                    rows[i].mid, rows[i].h, rows[i].nonmissing);
+    // chr start end mid h nonmissing (hetWindow.cpp:87)
+    write_rows(n_win, longest_name(runs) + 80, [&](size_t i, char *o) {
+        return (size_t)std::sprintf(o, "%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
+                                    rows[i].end, rows[i].mid, rows[i].h, rows[i].nonmissing);
+    });
+    timer.lap("print");
     return 0;
 }

@@ -275,6 +275,46 @@ size_t parse_table(const char *b, const char *e, Table &tab, Runs &runs, const c
     return n;
 }
 
+// ---- TSV writer -----------------------------------------------------------------------------
+// With -winsize 1 -stepsize 1 style runs (dxyWindow.cpp:47) the number of rows approaches the
+// number of sites and formatting becomes the bottleneck.  Rows are formatted by
+// all threads into per-thread buffers, one block of rows at a time, and the buffers are written in
+// row order.  fmt(i, out) must write row i (the same printf conversions the tools always used:
+// %g == default std::ostream precision, fstWindow.cpp:88) and return its length, at most
+// max_row_bytes.
+template <class Fmt>
+void write_rows(size_t n, size_t max_row_bytes, Fmt fmt, FILE *out = stdout) {
+    const int T = n < 200000 ? 1 : host_threads();
+    const size_t block = 1u << 20;  // rows per round
+    std::vector<std::vector<char>> buf(T);
+    std::vector<size_t> used(T);
+    for (size_t b0 = 0; b0 < n; b0 += block) {
+        const size_t b1 = std::min(n, b0 + block), per = (b1 - b0 + T - 1) / T;
+        auto work = [&](int t) {
+            const size_t r0 = std::min(b1, b0 + per * t), r1 = std::min(b1, r0 + per);
+            if (buf[t].size() < (r1 - r0) * max_row_bytes) buf[t].resize((r1 - r0) * max_row_bytes);
+            char *p = buf[t].data();
+            for (size_t i = r0; i < r1; ++i) p += fmt(i, p);
+            used[t] = (size_t)(p - buf[t].data());
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < T; ++t)
+            if (used[t] && std::fwrite(buf[t].data(), 1, used[t], out) != used[t]) die("write error on output");
+    }
+    std::fflush(out);
+}
+
+inline size_t longest_name(const Runs &r) {
+    size_t m = 0;
+    for (const auto &s : r.name) m = std::max(m, s.size());
+    return m;
+}
+
 inline int device_from_env() {
     const char *d = std::getenv("PGT_DEVICE");
     return d ? std::atoi(d) : 0;

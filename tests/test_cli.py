@@ -179,3 +179,27 @@ def test_dxy_cli_intersects_site_sets(hosts, tmp_path, oracle):
         assert r.returncode == 0, r.stderr
         tsv_equal(r.stdout, o.read_text(), 3)
         tsv_equal(r.stderr, e.read_text(), 0)
+
+
+@pytest.mark.gpu
+def test_cli_step_one_regime(hosts, tmp_path, oracle):
+    """S=1 (one window per site): O(N·W) for the reference, O(N·64·log W) here; the
+    block-parallel TSV writer must keep row order.  Checked against the oracle's text front end."""
+    import synth
+    rng = np.random.default_rng(6)
+    n, W = 250_000, 3_000
+    chr_ids, pos = synth.chromosomes(rng, n, 3, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n)
+    f, h, o = tmp_path / "fst.txt", tmp_path / "het.txt", tmp_path / "o.txt"
+    oracle.write_fst_text(str(f), chr_ids, pos, a, b)
+    oracle.write_het_text(str(h), chr_ids, pos, g)
+    r = run([hosts["fstWindow"], str(f), str(W), "1"])
+    assert r.returncode == 0, r.stderr
+    assert oracle.fst_text(str(f), W, 1, str(o)) == 0
+    assert len(r.stdout.splitlines()) > n - 3 * W
+    tsv_equal(r.stdout, o.read_text(), 4)
+    r = run([hosts["hetWindow"], str(h), str(W), "1"])
+    assert r.returncode == 0, r.stderr
+    assert oracle.het_text(str(h), W, 1, str(o)) == 0
+    assert r.stdout == o.read_text()  # integer counts: byte-identical

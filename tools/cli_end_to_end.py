@@ -51,7 +51,22 @@ def main():
             same, t_ref_s, sp = "n/a", "n/a", "n/a"
         phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
         print(f"| {tool} | {t_ref_s} | {t_new:.2f} | {sp} | {len(r_new.stdout.splitlines())} | {same} | {phases} |")
-    for p in (f_fst, f_het):
+    # S = 1: one window per site.  The reference re-sums W entries per site (O(N*W)); it is timed on
+    # a 10^5-site sample only.
+    m, W1 = 2_000_000, 50_000
+    f_s1, f_ref = os.path.join(d, "fst_s1.txt"), os.path.join(d, "fst_s1_ref.txt")
+    orc.write_fst_text(f_s1, chr_ids[:m], pos[:m], a[:m], b[:m])
+    orc.write_fst_text(f_ref, chr_ids[:100_000], pos[:100_000], a[:100_000], b[:100_000])
+    env = dict(os.environ, PGT_HOST_TIMING="1")
+    t_new, r_new = wall([os.path.join(BIN, "fstWindow"), f_s1, str(W1), "1"], env)
+    phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
+    print(f"\nS=1, W={W1}: this host, {m:.0e} sites -> {len(r_new.stdout.splitlines())} rows in {t_new:.2f} s "
+          f"({m / t_new:.3e} sites/s; {phases})")
+    ref = oracle_bind.ref_binary("fstWindow")
+    if ref:
+        t_ref, r_ref = wall([ref, f_ref, str(W1), "1"])
+        print(f"S=1, W={W1}: reference, 1e5-site sample -> {len(r_ref.stdout.splitlines())} rows in {t_ref:.2f} s ({1e5 / t_ref:.3e} sites/s)")
+    for p in (f_fst, f_het, f_s1, f_ref):
         os.unlink(p)
     os.rmdir(d)
 
