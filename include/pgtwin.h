@@ -150,6 +150,23 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
                              const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
                              size_t tree_bytes, void *stream);
 
+/* ---- allele-frequency front end ------------------------------------------ */
+/* Population allele frequencies -> Reynolds / Weir-Cockerham variance components exactly as WCFst()
+ * of the reference's betaAFOutlier.R:400-418 (per site a and a+b: the two columns fstWindow reads),
+ * then fstWindow's window statistic Σa / Σ(a+b) (fstWindow.cpp:76-85), for ALL pairs i<j of n_pops
+ * populations in one pass over the frequency columns (8 B/site/population instead of 16 B/site/pair).
+ *   freq   host array of n_pops DEVICE pointers: f64 allele frequency per site, 16-byte aligned
+ *   nsamp  host array of n_pops diploid sample sizes (the R arguments n1, n2)
+ *   out    n_pairs * n_win rows, pair-major, pairs ordered (0,1),(0,2),..,(0,n_pops-1),(1,2),..;
+ *          asum = Σa, bsum = Σ(a+b), n = sites in the window
+ *   tree   pgt_af_tree_bytes(n_pops, n) bytes.    2 <= n_pops <= 8.
+ * Parity note: the reference side is an R function with no runnable oracle in this image; the rows
+ * are checked against a literal C restatement of those lines (oracle/, parity unpinned). */
+size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites);
+int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
+                          uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
+                          void *tree, size_t tree_bytes, void *stream);
+
 /* ---- performance hint ------------------------------------------------------------------- */
 /* Longest window (in sites) the following *_dev calls will be asked for; 0 (the default) = unknown.
  * Tree levels whose nodes are larger than this are not built (a query never touches them).  The

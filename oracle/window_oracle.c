@@ -293,6 +293,26 @@ int orc_dxy_scan(const uint32_t *chr, const uint32_t *pos, const double *p1, con
 }
 
 /* ------------------------------------------------------------------------------------------
+ * betaAFOutlier.R:400-418, WCFst(): operation order as R evaluates it (left to right, ^2 == x*x)
+ * ---------------------------------------------------------------------------------------- */
+void orc_wcfst_site(double f1, double f2, double n1, double n2, double *a_out, double *ab_out) {
+    const double npool = n1 + n2;                                      /* :406 */
+    const double fpool = n1 / npool * f1 + n2 / npool * f2;            /* :407 */
+    const double alpha1 = 2 * f1 * (1 - f1);                           /* :408 */
+    const double alpha2 = 2 * f2 * (1 - f2);                           /* :409 */
+    const double b = (n1 * alpha1 + n2 * alpha2) / (npool - 1);        /* :410 */
+    const double d1 = f1 - fpool, d2 = f2 - fpool;
+    const double a = (4 * n1 * (d1 * d1) + 4 * n2 * (d2 * d2) - b) / (4 * n1 * n2 / npool); /* :411 */
+    *a_out = a;
+    *ab_out = b + a;                                                   /* :416 varcomp[,2]+varcomp[,1] */
+}
+
+void orc_wcfst_columns(const double *f1, const double *f2, size_t n, double n1, double n2, double *a,
+                       double *ab) {
+    for (size_t i = 0; i < n; ++i) orc_wcfst_site(f1[i], f2[i], n1, n2, &a[i], &ab[i]);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Text front ends
  * ---------------------------------------------------------------------------------------- */
 typedef struct {

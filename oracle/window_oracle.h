@@ -75,6 +75,16 @@ int orc_dxy_scan(const uint32_t *chr, const uint32_t *pos, const double *p1, con
                  int minind, int fixedsite, int skip_missing, const uint32_t *run_chr_len,
                  size_t n_runs, orc_row *out, size_t cap, size_t *n_out, orc_dxy_total *tot);
 
+/* Allele-frequency front end.  WCFst() of betaAFOutlier.R:400-418, restated
+ * literally: per site, from the allele frequencies f1, f2 of two populations with diploid sample
+ * sizes n1, n2 (scalars), the Reynolds/Weir-Cockerham components (a, a+b) — the two columns
+ * fstWindow consumes.  PARITY UNPINNED: the reference is an R script, Rscript is absent from this
+ * image, and the reference holds no test vector for it; the formula at those lines is the spec. */
+void orc_wcfst_site(double f1, double f2, double n1, double n2, double *a, double *a_plus_b);
+/* a[i], ab[i] for every site (betaAFOutlier.R:415-417) */
+void orc_wcfst_columns(const double *f1, const double *f2, size_t n, double n1, double n2,
+                       double *a, double *ab);
+
 /* Text front ends: same argv meaning and TSV as the reference tools, written to `out`
  * (and `err` for the dxy genome-wide line, dxyWindow.cpp:429-433).  Used for byte parity with
  * oracle/_ref and as the "port" CPU baseline when oracle/_ref is absent. */

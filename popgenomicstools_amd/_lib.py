@@ -38,7 +38,7 @@ SYMBOLS = [
     "pgt_build_windows_sites", "pgt_build_windows_bp",
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
-    "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_set_max_window", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
+    "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
 ]
 
 
@@ -88,6 +88,9 @@ def load() -> C.CDLL:
     lib.pgt_dxy_reduce_dev.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp, vp, sz, vp]
     lib.pgt_fst_reduce_pairs_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
     lib.pgt_dxy_het_reduce_dev.argtypes = [vp] * 8 + [u64, i32, vp, u64, vp, vp, vp, vp, vp, sz, vp]
+    lib.pgt_af_tree_bytes.restype = sz
+    lib.pgt_af_tree_bytes.argtypes = [u32, u64]
+    lib.pgt_fst_af_reduce_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
     lib.pgt_set_max_window.argtypes = [vp, u64]
     lib.pgt_set_profiling.argtypes = [vp, i32]
     lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -18,7 +18,7 @@ HOST = os.path.join(PKG, "host")
 BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libpgtwin.so")
 
-LIB_SOURCES = ["pgt_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
+LIB_SOURCES = ["pgt_kernels.hip", "pgt_af_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
 HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow"]
 
 
@@ -45,7 +45,7 @@ def _run(cmd: list[str]) -> None:
 
 def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(ROOT, "include", "pgtwin.h")]
+    deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(CSRC, "pgt_device.h"), os.path.join(ROOT, "include", "pgtwin.h")]
     if force or _newer(LIB, deps):
         extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPGT_TUNING_BUILD for tools/tune_build.py
         _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -1,0 +1,333 @@
+// pgt_af_kernels.hip — allele-frequency front end: population allele frequencies
+// -> Reynolds / Weir-Cockerham variance components -> the fstWindow reduction, for ALL pairs of up
+// to 8 populations in one pass over the frequency columns.
+//
+// Spec: WCFst() of the reference's betaAFOutlier.R:400-418 — per site and pair (1,2)
+//     npool = n1+n2;  fpool = n1/npool*f1 + n2/npool*f2;  alpha_k = 2*f_k*(1-f_k)
+//     b = (n1*alpha1 + n2*alpha2)/(npool-1)
+//     a = (4*n1*(f1-fpool)^2 + 4*n2*(f2-fpool)^2 - b)/(4*n1*n2/npool)
+// and fstWindow's window statistic Σa / Σ(a+b) (fstWindow.cpp:76-85 on the columns a, a+b that
+// betaAFOutlier.R:415-417 returns).
+//
+// Since f1-fpool = (n2/npool)(f1-f2) and f2-fpool = -(n1/npool)(f1-f2), the numerator's first two
+// terms are exactly (4*n1*n2/npool)(f1-f2)^2, hence a = (f1-f2)^2 - b*npool/(4*n1*n2): window sums
+// of every pair follow from  A_k = Σ 2 f_k (1-f_k)  (one per population) and  D_ij = Σ (f_i-f_j)^2
+// (one per pair):   Σb = (n_i A_i + n_j A_j)/(npool-1),   Σa = D_ij - Σb * npool/(4 n_i n_j).
+// So the tree carries V = NP + NP(NP-1)/2 scalar sums per node (36 for 8 populations) and the
+// build streams 8 B/site/population (64 B/site for 8 populations) instead of the 16 B/site/pair
+// (448 B/site for 28 pairs) of precomputed component columns.
+//
+// Cross-lane cost: V sums per 128-site leaf tile would be V six-step butterflies; instead a
+// REDUCE-SCATTER halves the live values at every exchange step (18+9+5+3+2+1 = 38 exchanges for
+// V = 36), leaving each total in exactly one lane, which stores it and keeps the level-2 running sum.
+#include <hip/hip_runtime.h>
+
+#include "pgt_device.h"
+#include "pgt_internal.h"
+
+namespace pgt {
+namespace {
+
+using namespace dev;
+
+template <int NP>
+struct Shape {
+    static constexpr int kPairs = NP * (NP - 1) / 2;
+    static constexpr int kVals = NP + kPairs;  // A_0..A_{NP-1}, then D_ij in lexicographic (i<j) order
+};
+
+struct AfCols {
+    const double *f[kAfMaxPops];
+    double nsamp[kAfMaxPops];
+};
+
+// ---- exchange with lane ^ mask, cheapest mechanism per mask ------------------------------------
+constexpr int kRsMask[6] = {1, 2, 8, 4, 16, 32};  // order: the steps with most exchanges use DPP
+template <int STEP>
+__device__ __forceinline__ double xchg(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (STEP == 0) {         // xor 1: quad_perm [1,0,3,2]
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    } else if constexpr (STEP == 1) {  // xor 2: quad_perm [2,3,0,1]
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    } else if constexpr (STEP == 2) {  // xor 8: row_ror:8 inside the 16-lane row
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
+    } else if constexpr (STEP == 3) {  // xor 4: ds_swizzle bit mode (and 0x1f, or 0, xor 4)
+        lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F);
+        hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);
+    } else if constexpr (STEP == 4) {  // xor 16: ds_swizzle bit mode
+        lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+        hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+    } else {                           // xor 32: across the two 32-lane halves
+        lo = __shfl_xor(lo, 32, kWave);
+        hi = __shfl_xor(hi, 32, kWave);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// One reduce-scatter step: C live values -> (C+1)/2.  A lane whose mask bit is set keeps the upper
+// half and sends the lower half, its partner does the opposite; an odd C is padded with 0.
+template <int C, int STEP>
+__device__ __forceinline__ void rs_steps(double *v, int lane) {
+    if constexpr (STEP < 6) {
+        constexpr int H = (C + 1) / 2;
+        const bool up = (lane & kRsMask[STEP]) != 0;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double lo_v = v[k];
+            const double hi_v = (k + H < C) ? v[k + H] : 0.0;
+            const double keep = up ? hi_v : lo_v;
+            const double send = up ? lo_v : hi_v;
+            v[k] = keep + xchg<STEP>(send);
+        }
+        rs_steps<H, STEP + 1>(v, lane);
+    }
+}
+
+// Which of the V values ends up in this lane (-1: a padding slot)
+template <int V>
+__device__ __forceinline__ int rs_my_index(int lane) {
+    int base = 0, real = V, c = V;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int H = (c + 1) / 2;
+        if (lane & kRsMask[s]) { base += H; real = real > H ? real - H : 0; }
+        else real = real < H ? real : H;
+        c = H;
+    }
+    return real >= 1 ? base : -1;
+}
+
+// ---- per-site contributions ----------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void af_accumulate(double *vals, const double *f) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vals[i] += (2.0 * f[i]) * (1.0 - f[i]);  // alpha_i, betaAFOutlier.R:408-409
+    int p = NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = i + 1; j < NP; ++j) {
+            const double d = f[i] - f[j];
+            vals[p++] += d * d;
+        }
+}
+
+__device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int v, uint64_t i) {
+    return reinterpret_cast<double *>(tv.base + tv.off[level_slot] + (size_t)v * tv.stride[level_slot]) + i;
+}
+
+// ---- BUILD: one wave per level-2 tile (64 leaf tiles of 128 sites) ------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
+    constexpr int V = Shape<NP>::kVals;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int my = rs_my_index<V>(lane);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        const bool full = base + kTile2 <= n;
+        double l2acc = 0.0;
+        double2 cur[NP];
+        auto load_tile = [&](double2 *dst, int j) {
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    dst[k] = load16<true>(reinterpret_cast<const double2 *>(cols.f[k] + base) + j * kWave + lane);
+            } else {  // last, partial level-2 tile: guarded loads; f = 0 contributes nothing
+                const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    dst[k].x = i0 < n ? cols.f[k][i0] : 0.0;
+                    dst[k].y = i0 + 1 < n ? cols.f[k][i0 + 1] : 0.0;
+                }
+            }
+        };
+        load_tile(cur, 0);
+#pragma unroll 2
+        for (int j = 0; j < kRadix; ++j) {
+            double2 nxt[NP];
+            if (j + 1 < kRadix) load_tile(nxt, j + 1);  // next tile's loads fly while this one is reduced
+            double vals[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) vals[v] = 0.0;
+            double fx[NP], fy[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
+            af_accumulate<NP>(vals, fx);
+            af_accumulate<NP>(vals, fy);
+            rs_steps<V, 0>(vals, lane);
+            if (my >= 0) {
+                *af_node(tv, 0, my, t * kRadix + j) = vals[0];
+                l2acc += vals[0];
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
+        }
+        if (my >= 0) *af_node(tv, 1, my, t) = l2acc;
+    }
+}
+
+// ---- upper levels: parent = Σ of 64 children, per value (blockIdx.y) -----------------------------
+__global__ __launch_bounds__(256) void af_up_kernel(AfTree tv, int child_slot, uint64_t n_child, uint64_t n_parent) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int v = blockIdx.y;
+    for (uint64_t p = wave0; p < n_parent; p += n_waves) {
+        const uint64_t i = p * kRadix + lane;
+        double x = i < n_child ? *af_node(tv, child_slot, v, i) : 0.0;
+        x = wave_sum(x);
+        if (lane == 0) *af_node(tv, child_slot + 1, v, p) = x;
+    }
+}
+
+// ---- QUERY: one wave per window, all pairs at once ---------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32_t *__restrict__ pos, AfTree tv,
+                                                       const pgt_win *__restrict__ win, uint64_t n_win,
+                                                       pgt_fst_row *__restrict__ out, uint64_t n_sites) {
+    constexpr int V = Shape<NP>::kVals;
+    constexpr int P = Shape<NP>::kPairs;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (uint64_t w = wave0; w < n_win; w += n_waves) {
+        const pgt_win wd = win[w];
+        const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
+        const uint64_t lo = wd.lo < hi ? wd.lo : hi;
+        double acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = 0.0;
+        auto sum_sites = [&](uint64_t from, uint64_t to) {
+            for (uint64_t i = from + lane; i < to; i += kWave) {
+                double f[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) f[k] = cols.f[k][i];
+                af_accumulate<NP>(acc, f);
+            }
+        };
+        auto sum_nodes = [&](int level, uint64_t from, uint64_t to) {
+            for (uint64_t i = from + lane; i < to; i += kWave) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] += *af_node(tv, level - 1, v, i);
+            }
+        };
+        uint64_t clo = lo, chi = hi;
+        for (int k = 0;; ++k) {
+            const bool top = k == tv.n_levels;
+            const uint64_t r = k == 0 ? (uint64_t)kLeafF64 : (uint64_t)kRadix;
+            const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
+            if (top || ulo >= uhi) {
+                if (k == 0) sum_sites(clo, chi); else sum_nodes(k, clo, chi);
+                break;
+            }
+            if (k == 0) { sum_sites(clo, ulo * r); sum_sites(uhi * r, chi); }
+            else { sum_nodes(k, clo, ulo * r); sum_nodes(k, uhi * r, chi); }
+            clo = ulo;
+            chi = uhi;
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = wave_sum(acc[v]);  // every lane holds every total
+        // lanes 0..P-1 each finish one pair (i<j, lexicographic)
+        int pi = 0, pj = 1, p = 0;
+        double Ai = 0.0, Aj = 0.0, D = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int j = i + 1; j < NP; ++j) {
+                if (p == lane) { pi = i; pj = j; Ai = acc[i]; Aj = acc[j]; D = acc[NP + p]; }
+                ++p;
+            }
+        if (lane < P) {
+            const double ni = cols.nsamp[pi], nj = cols.nsamp[pj], npool = ni + nj;
+            const double sb = (ni * Ai + nj * Aj) / (npool - 1.0);      // Σb, betaAFOutlier.R:410
+            const double sa = D - sb * (npool / (4.0 * ni * nj));       // Σa, betaAFOutlier.R:411 (see header)
+            pgt_fst_row r;
+            uint32_t start = wd.start, end = wd.end;
+            if (!(wd.flags & PGT_WIN_COORDS)) {
+                start = hi > lo ? pos[lo] : 0u;
+                end = hi > lo ? pos[hi - 1] : 0u;
+            }
+            r.start = start;
+            r.end = end;
+            r.mid = (uint32_t)(start + end) / 2u;      // fstWindow.cpp:73
+            r.n = (uint32_t)(hi - lo);
+            r.asum = sa + 0.0;
+            r.bsum = (sa + sb) + 0.0;                    // Σ(a+b): the tool's second column
+            r.fst = r.bsum != 0.0 ? r.asum / r.bsum : 0.0;  // fstWindow.cpp:85
+            out[(uint64_t)lane * n_win + w] = r;
+        }
+    }
+}
+
+inline int hip_fail(hipError_t e, const char *what, std::string *err) {
+    if (e == hipSuccess) return PGT_OK;
+    if (err) *err = std::string(what) + ": " + hipGetErrorString(e);
+    return PGT_EDEVICE;
+}
+
+template <int NP>
+int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_win *win, uint64_t n_win,
+                 pgt_fst_row *out, const AfTree &tv, const TreeLayout &tl, hipStream_t s, void *ev_b0, void *ev_b1,
+                 void *ev_q1, std::string *err) {
+    auto rec = [&](void *ev) {
+        return ev ? hip_fail(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord", err) : PGT_OK;
+    };
+    if (int rc = rec(ev_b0)) return rc;
+    if (n > 0) {
+        uint64_t blocks = (tl.count[1] + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), 0, s, cols, n, tl.count[1], tv);
+        if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
+        for (int k = 2; k < tv.n_levels; ++k) {
+            uint64_t b = (tl.count[k] + 3) / 4;
+            if (b > 65536) b = 65536;
+            hipLaunchKernelGGL(af_up_kernel, dim3((unsigned)b, Shape<NP>::kVals), dim3(256), 0, s, tv, k - 1,
+                               tl.count[k - 1], tl.count[k]);
+            if (int rc = hip_fail(hipGetLastError(), "af_up_kernel", err)) return rc;
+        }
+    }
+    if (int rc = rec(ev_b1)) return rc;
+    if (n_win > 0) {
+        uint64_t b = (n_win + 3) / 4;
+        if (b > 65536) b = 65536;
+        hipLaunchKernelGGL((af_query_kernel<NP>), dim3((unsigned)b), dim3(256), 0, s, cols, pos, tv, win, n_win, out, n);
+        if (int rc = hip_fail(hipGetLastError(), "af_query_kernel", err)) return rc;
+    }
+    return rec(ev_q1);
+}
+
+}  // namespace
+
+int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops, uint64_t n,
+                  const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream, void *ev_build0,
+                  void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
+    const int n_vals = (int)(n_pops + n_pops * (n_pops - 1) / 2);
+    const AfTree tv = af_tree_view(tl, n_vals, tree, useful_levels(tl, PGT_STAT_FST, max_window));
+    AfCols cols{};
+    for (uint32_t k = 0; k < n_pops; ++k) { cols.f[k] = freq[k]; cols.nsamp[k] = nsamp[k]; }
+    switch (n_pops) {
+        case 2: return launch_af_np<2>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 3: return launch_af_np<3>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 4: return launch_af_np<4>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 5: return launch_af_np<5>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 6: return launch_af_np<6>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 7: return launch_af_np<7>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        case 8: return launch_af_np<8>(cols, pos, n, win, n_win, out, tv, tl, s, ev_build0, ev_build1, ev_query1, err);
+        default:
+            if (err) *err = "pgt_fst_af_reduce: 2 <= n_pops <= 8";
+            return PGT_EARG;
+    }
+}
+
+}  // namespace pgt

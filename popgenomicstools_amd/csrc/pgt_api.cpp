@@ -247,6 +247,30 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
                           stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
 }
 
+size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites) {
+    if (n_pops < 2 || n_pops > (uint32_t)kAfMaxPops) return 0;
+    return af_tree_bytes(tree_layout(PGT_STAT_FST, n_sites), (int)(n_pops + n_pops * (n_pops - 1) / 2));
+}
+
+int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
+                          uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
+                          size_t tree_bytes, void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!freq || !nsamp || !tree || (n_win && (!win || !out || !pos)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: NULL argument");
+    if (n_pops < 2 || n_pops > (uint32_t)kAfMaxPops) return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: 2 <= n_pops <= 8");
+    for (uint32_t k = 0; k < n_pops; ++k) {
+        if (!freq[k] || !aligned16(freq[k]))
+            return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: frequency columns must be non-NULL and 16-byte aligned");
+        if (!(nsamp[k] > 0.0)) return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: sample sizes must be positive");
+    }
+    if (!aligned16(tree) || tree_bytes < pgt_af_tree_bytes(n_pops, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_fst_af(pos, freq, nsamp, n_pops, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
+                         ctx->max_window);
+}
+
 /* ---------------- host-buffer entry points ---------------- */
 
 int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,

@@ -74,6 +74,33 @@ inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
     return k;
 }
 
+// ---- allele-frequency front end (pgt_af_kernels.hip): V scalar trees, structure-of-arrays -----
+constexpr int kAfMaxPops = 8;
+struct AfTree {
+    char *base;
+    size_t off[kMaxLevels];     // byte offset of level slot k (all V value arrays of that level)
+    size_t stride[kMaxLevels];  // bytes between consecutive value arrays inside level slot k
+    int n_levels;
+};
+inline size_t af_level_stride(const TreeLayout &t, int k) { return ((t.count[k] * 8 + 255) / 256) * 256; }
+inline size_t af_tree_bytes(const TreeLayout &t, int n_vals) {
+    size_t b = 0;
+    for (int k = 0; k < t.n_levels; ++k) b += (size_t)n_vals * af_level_stride(t, k);
+    return b;
+}
+inline AfTree af_tree_view(const TreeLayout &t, int n_vals, void *tree, int levels) {
+    AfTree v{};
+    v.base = static_cast<char *>(tree);
+    v.n_levels = levels;
+    size_t off = 0;
+    for (int k = 0; k < t.n_levels; ++k) {
+        v.off[k] = off;
+        v.stride[k] = af_level_stride(t, k);
+        off += (size_t)n_vals * v.stride[k];
+    }
+    return v;
+}
+
 // ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
@@ -91,6 +118,10 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
                    const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
                    pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, void *stream,
                    void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
+
+int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops,
+                  uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
+                  void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 
 // thread-local message for the ctx-less entry points
 void set_global_error(const std::string &msg);

@@ -253,6 +253,27 @@ class Context:
             self._stream(stream)))
         return dxy_out, tot, h1, h2, tree
 
+    def fst_af_reduce_dev(self, pos, freqs, nsamp, win, out=None, tree=None, stream=None):
+        """Allele frequencies of len(freqs) populations -> FST rows of all pairs i<j (pair-major),
+        WCFst() of betaAFOutlier.R:400-418 + fstWindow's Σa/Σ(a+b).  freqs: float64 CUDA tensors."""
+        import torch
+        n_pops = len(freqs)
+        n = freqs[0].numel()
+        n_pairs = n_pops * (n_pops - 1) // 2
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        tb = int(self._lib.pgt_af_tree_bytes(n_pops, n))
+        if tree is None:
+            tree = torch.empty(tb, dtype=torch.uint8, device=pos.device)
+        if out is None:
+            out = torch.empty(n_pairs * n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=pos.device)
+        pf = (C.c_void_p * n_pops)(*[self._dev(t, torch.float64, "freq") for t in freqs])
+        ns = (C.c_double * n_pops)(*[float(x) for x in nsamp])
+        self._check(self._lib.pgt_fst_af_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), pf, ns, n_pops, n, self._dev(win, torch.uint8, "win"),
+            n_win, self._dev(out, torch.uint8, "out"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
+            self._stream(stream)))
+        return out, tree
+
     def set_max_window(self, sites: int):
         """Performance hint for the *_dev calls: no window is longer than `sites` (0 = unknown)."""
         self._check(self._lib.pgt_set_max_window(self._ctx, int(sites)))

@@ -87,6 +87,17 @@ class Oracle:
             (p.size + slots) // max(S, 1) + 64)
         return rows, tot[0]
 
+    def wcfst_columns(self, f1, f2, n1, n2):
+        """betaAFOutlier.R:400-418 per site -> (a, a+b) columns (parity unpinned, see window_oracle.h)."""
+        f1 = np.ascontiguousarray(f1, dtype=np.float64)
+        f2 = np.ascontiguousarray(f2, dtype=np.float64)
+        a, ab = np.empty_like(f1), np.empty_like(f1)
+        f = self.lib.orc_wcfst_columns
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(f1.ctypes.data, f2.ctypes.data, f1.size, float(n1), float(n2), a.ctypes.data, ab.ctypes.data)
+        return a, ab
+
     # text front ends ----------------------------------------------------------------------
     def fst_text(self, path, W, S, out_path):
         f = self.lib.orc_fst_text_path

@@ -435,3 +435,61 @@ def test_max_window_hint_only_changes_speed(pgt, ctx):
         assert np.array_equal(low[f], base[f])
     assert_close(low["fst"], base["fst"], "fst under a too-small hint")
     assert_close(low["asum"], base["asum"], "asum under a too-small hint")
+
+
+# ---------------------------------------------------------------------------------------------
+# allele-frequency front end: WCFst() of betaAFOutlier.R:400-418 + fstWindow
+# ---------------------------------------------------------------------------------------------
+def _af_rows(ctx, pos, freqs, nsamp, win):
+    import torch
+    dev = torch.device("cuda:0")
+    out, _ = ctx.fst_af_reduce_dev(torch.from_numpy(pos.view(np.int32)).to(dev),
+                                   [torch.from_numpy(f).to(dev) for f in freqs], nsamp, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    n_pairs = len(freqs) * (len(freqs) - 1) // 2
+    return rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+
+
+@pytest.mark.parametrize("n_pops,n,W,S", [(2, 1, 1, 1), (2, 127, 50, 7), (2, 300_000, 50_000, 10_000), (3, 8193, 1000, 1000),
+                                          (4, 129, 128, 1), (5, 70_000, 9_000, 4_000), (8, 16_385, 5_000, 2_500),
+                                          (8, 700_001, 50_000, 10_000), (8, 1_200_000, 600_000, 300_000)])
+def test_af_front_end_vs_oracle(pgt, ctx, oracle, n_pops, n, W, S):
+    """All pairs from the frequency columns == fstWindow (oracle, sequential sums) run on the (a, a+b)
+    columns that the literal restatement of WCFst() produces for that pair."""
+    rng = np.random.default_rng(1000 * n_pops + n % 997)
+    chr_ids, pos = synth.chromosomes(rng, n, min(n, 3), equal=False)
+    base = rng.uniform(0.02, 0.98, n)
+    freqs = [np.clip(np.round(base + rng.normal(0, 0.08, n), 6), 0.0, 1.0) for _ in range(n_pops)]
+    nsamp = [float(x) for x in rng.integers(5, 40, n_pops)]
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+    rows = _af_rows(ctx, pos, freqs, nsamp, win)
+    p = 0
+    for i in range(n_pops):
+        for j in range(i + 1, n_pops):
+            a, ab = oracle.wcfst_columns(freqs[i], freqs[j], nsamp[i], nsamp[j])
+            ref = oracle.fst_scan(chr_ids, pos, a, ab, W, S)
+            r = rows[p]
+            assert r.size == ref.size
+            for f in ("start", "end", "mid", "n"):
+                assert np.array_equal(r[f], ref[f])
+            # Σ(a+b) is a sum of positives: relative 1e-9.  Σa cancels (a is negative where the
+            # populations agree), so its error is measured against Σ(a+b), as is the ratio's.
+            assert_close(r["bsum"], ref["den"], f"pair {i},{j} Σ(a+b)")
+            assert np.all(np.abs(r["asum"] - ref["num"]) <= 1e-9 * np.abs(ref["den"]) + 1e-12)
+            assert np.all(np.abs(r["fst"] - ref["value"]) <= 1e-9)
+            p += 1
+    assert p == rows.shape[0]
+
+
+def test_af_front_end_equals_component_path(pgt, ctx, oracle):
+    """Feeding the restated (a, a+b) columns through the ordinary fst path gives the same rows (1e-9)."""
+    rng = np.random.default_rng(77)
+    n = 400_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4)
+    f1, f2 = np.round(rng.uniform(0, 1, n), 6), np.round(rng.uniform(0, 1, n), 6)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    af = _af_rows(ctx, pos, [f1, f2], [12.0, 20.0], win)[0]
+    a, ab = oracle.wcfst_columns(f1, f2, 12.0, 20.0)
+    comp = ctx.fst_reduce(pos, a, ab, win)
+    assert_close(af["bsum"], comp["bsum"], "Σ(a+b)")
+    assert np.all(np.abs(af["fst"] - comp["fst"]) <= 1e-9)

@@ -68,6 +68,15 @@ def main():
     bl = [b] + [b.roll(1000 * (k + 1)) for k in range(n_pairs - 1)]
     row("5: fstWindow 28 pairs x 1e8 (one GPU)", 448, timed(ctx, lambda: ctx.fst_reduce_pairs_dev(pos, al, bl, win, out=out, tree=tree), reps=6))
     del al, bl
+    # the same 28 pairs from 8 allele-frequency columns: 64 B/site streamed
+    fr = [torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 1e6) / 1e6 for _ in range(8)]
+    nsamp = [10.0 + k for k in range(8)]
+    af_tree = torch.empty(int(pgt._lib.load().pgt_af_tree_bytes(8, n)), dtype=torch.uint8, device=dev)
+    row("5': 28 pairs from 8 frequency columns x 1e8 (pgt_fst_af_reduce_dev)", 64,
+        timed(ctx, lambda: ctx.fst_af_reduce_dev(pos, fr, nsamp, win, out=out, tree=af_tree), reps=6))
+    row("AF front end, 2 populations x 1e8", 16,
+        timed(ctx, lambda: ctx.fst_af_reduce_dev(pos, fr[:2], nsamp[:2], win, out=out, tree=af_tree)))
+    del fr, af_tree
     # host-buffer entry point: H2D of 20 B/site + kernels + D2H, synchronous
     m = 50_000_000
     hp, ha, hb = pos[:m].cpu().numpy().view(np.uint32), a[:m].cpu().numpy(), b[:m].cpu().numpy()
