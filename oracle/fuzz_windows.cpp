@@ -1,0 +1,78 @@
+// fuzz_windows.cpp — native differential fuzzer, TEST INFRASTRUCTURE ONLY.
+// Links the product's host-only window-table builders (popgenomicstools_amd/csrc/pgt_windows.cpp)
+// against the oracle's streaming machine (oracle/window_oracle.c) and compares them on random
+// chromosome layouts, in both site-count and bp-slot mode.  Built with
+//   -fsanitize=address,undefined   (tests/test_sanitizers.py)
+// so that the builders' index arithmetic is also checked for out-of-bounds / UB on the CPU (GPU
+// sanitizers are not available on this pool).
+//   usage: fuzz_windows [trials] [seed]        exit 0 = all equal
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#include "pgtwin.h"
+#include "window_oracle.h"
+
+static int fail(const char *what, int trial) {
+    std::fprintf(stderr, "MISMATCH (%s) in trial %d\n", what, trial);
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    const int trials = argc > 1 ? std::atoi(argv[1]) : 2000;
+    std::mt19937_64 rng(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 12345);
+    auto U = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
+    size_t windows = 0;
+    for (int t = 0; t < trials; ++t) {
+        const uint32_t W = (uint32_t)U(1, 40), S = (uint32_t)U(1, (int)W);
+        const int n_runs = U(1, 6);
+        std::vector<uint64_t> run_len(n_runs);
+        std::vector<uint32_t> chr_len(n_runs), chr, pos;
+        for (int r = 0; r < n_runs; ++r) {
+            const int L = U(1, 120), k = U(1, L < 30 ? L : 30);
+            std::vector<int> all(L);
+            for (int i = 0; i < L; ++i) all[i] = i + 1;
+            for (int i = 0; i < k; ++i) std::swap(all[i], all[i + rng() % (uint64_t)(L - i)]);
+            std::vector<int> p(all.begin(), all.begin() + k);
+            std::sort(p.begin(), p.end());
+            run_len[r] = (uint64_t)k;
+            chr_len[r] = (uint32_t)(rng() % 7 == 0 ? std::max(1, p.back() - U(0, 3)) : L);  // sometimes shorter than the data
+            for (int x : p) { pos.push_back((uint32_t)x); chr.push_back((uint32_t)r); }
+        }
+        const size_t n = pos.size();
+        std::vector<double> ones(n, 1.0);
+        std::vector<int32_t> nind(n, 9);
+        // ---- site mode
+        size_t n_out = 0, n_ref = 0;
+        if (pgt_build_windows_sites(run_len.data(), run_len.size(), W, S, nullptr, 0, &n_out) != PGT_OK) return fail("sites count", t);
+        std::vector<pgt_win> win(n_out + 1);
+        if (pgt_build_windows_sites(run_len.data(), run_len.size(), W, S, win.data(), win.size(), &n_out) != PGT_OK) return fail("sites fill", t);
+        std::vector<orc_row> ref(n + 8);
+        if (orc_fst_scan(chr.data(), pos.data(), ones.data(), ones.data(), n, W, S, ref.data(), ref.size(), &n_ref) != ORC_OK) return fail("oracle fst", t);
+        if (n_ref != n_out) return fail("site window count", t);
+        for (size_t i = 0; i < n_out; ++i)
+            if (win[i].lo != ref[i].lo || win[i].hi != ref[i].hi || win[i].label_run != ref[i].label) return fail("site window", t);
+        windows += n_out;
+        // ---- bp mode
+        if (pgt_build_windows_bp(pos.data(), run_len.data(), chr_len.data(), run_len.size(), W, S, nullptr, 0, &n_out) != PGT_OK) return fail("bp count", t);
+        std::vector<pgt_win> bwin(n_out + 1);
+        if (pgt_build_windows_bp(pos.data(), run_len.data(), chr_len.data(), run_len.size(), W, S, bwin.data(), bwin.size(), &n_out) != PGT_OK) return fail("bp fill", t);
+        size_t slots = 0;
+        for (int r = 0; r < n_runs; ++r) slots += chr_len[r] + 130;
+        std::vector<orc_row> bref(slots + 8);
+        orc_dxy_total tot;
+        if (orc_dxy_scan(chr.data(), pos.data(), ones.data(), ones.data(), nind.data(), nind.data(), n, W, S, 1, 0, 0,
+                         chr_len.data(), chr_len.size(), bref.data(), bref.size(), &n_ref, &tot) != ORC_OK) return fail("oracle dxy", t);
+        if (n_ref != n_out) return fail("bp window count", t);
+        for (size_t i = 0; i < n_out; ++i) {
+            if (bwin[i].start != bref[i].start || bwin[i].end != bref[i].end || bwin[i].label_run != bref[i].label) return fail("bp coords", t);
+            if (bref[i].hi > bref[i].lo && (bwin[i].lo != bref[i].lo || bwin[i].hi != bref[i].hi)) return fail("bp sites", t);
+            if (bref[i].hi == bref[i].lo && bwin[i].lo != bwin[i].hi) return fail("bp empty", t);
+        }
+        windows += n_out;
+    }
+    std::printf("fuzz_windows: %d trials, %zu windows, all equal\n", trials, windows);
+    return 0;
+}

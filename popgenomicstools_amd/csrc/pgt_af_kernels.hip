@@ -105,14 +105,15 @@ __device__ __forceinline__ int rs_my_index(int lane) {
 template <int NP>
 __device__ __forceinline__ void af_accumulate(double *vals, const double *f) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) vals[i] += (2.0 * f[i]) * (1.0 - f[i]);  // alpha_i, betaAFOutlier.R:408-409
+    for (int i = 0; i < NP; ++i) vals[i] = fma(2.0 * f[i], 1.0 - f[i], vals[i]);  // alpha_i, betaAFOutlier.R:408-409
     int p = NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
         for (int j = i + 1; j < NP; ++j) {
             const double d = f[i] - f[j];
-            vals[p++] += d * d;
+            vals[p] = fma(d, d, vals[p]);  // explicit FMA: one op, one rounding (the TU is built with -ffp-contract=off)
+            ++p;
         }
 }
 
