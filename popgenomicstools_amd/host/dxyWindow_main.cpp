@@ -112,6 +112,7 @@ int main(int argc, char **argv) {
     }
 
     PhaseTimer timer;
+    DeviceOpener device;  // HIP start-up runs beside the parse
     Maf m1, m2;
     {   // the two files are independent: parse them side by side
         std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1); });
@@ -176,12 +177,11 @@ int main(int argc, char **argv) {
     }
 
     timer.lap("sync + table");
-    pgt_ctx *ctx = open_or_die();
+    pgt_ctx *ctx = device.get();
     std::vector<pgt_dxy_row> rows(win.size());
     pgt_dxy_total tot{};
     check(pgt_dxy_reduce(ctx, pos.data(), p1.data(), p2.data(), n1.data(), n2.data(), pos.size(), minind, win.data(),
                          win.size(), rows.data(), &tot), ctx);
-    pgt_close(ctx);
     timer.lap("gpu reduce");
 
     // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)

@@ -26,6 +26,7 @@ int main(int argc, char **argv) {
     Text text;
     if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
     parse_window_args(argc, argv, W, S);
+    DeviceOpener device;  // HIP start-up runs beside the parse
 
     // chr pos a b  (fstWindow.cpp:130,141), parsed in parallel chunks straight into the columns
     struct Table {
@@ -49,11 +50,10 @@ int main(int argc, char **argv) {
     std::vector<pgt_win> win(n_win);
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
 
-    pgt_ctx *ctx = open_or_die();
+    pgt_ctx *ctx = device.get();
     std::vector<pgt_fst_row> rows(n_win);
     timer.lap("window table");
     check(pgt_fst_reduce(ctx, tab.pos.data(), tab.a.data(), tab.b.data(), n, win.data(), n_win, rows.data()), ctx);
-    pgt_close(ctx);
     timer.lap("gpu reduce");
 
     // chr start end mid fst nsites; %g == std::ostream default formatting (fstWindow.cpp:88)

@@ -38,9 +38,13 @@
 namespace pgthost {
 
 // The reference tools `return -1` from main on error, i.e. exit status 255.
+// _exit, not exit: a background thread may still be inside HIP start-up (DeviceOpener), and running
+// static destructors under it is not safe; nothing of value is buffered at this point.
 [[noreturn]] inline void die(const std::string &msg) {
+    std::fflush(stdout);
     std::fprintf(stderr, "%s\n", msg.c_str());
-    std::exit(255);
+    std::fflush(stderr);
+    _exit(255);
 }
 
 inline void check(int rc, const pgt_ctx *ctx) {
@@ -325,6 +329,31 @@ inline pgt_ctx *open_or_die() {
     if (!ctx) die(std::string("libpgtwin: ") + pgt_last_error(nullptr));
     return ctx;
 }
+
+// HIP start-up (50-160 ms) overlapped with parsing: the device is opened on a background thread as
+// soon as the arguments are known to be valid; get() joins it.  Inputs that produce no window never
+// call get() and therefore still run without a GPU, as before.
+class DeviceOpener {
+  public:
+    DeviceOpener() : th_([this] {
+        ctx_ = pgt_open(device_from_env());
+        if (!ctx_) err_ = pgt_last_error(nullptr);  // thread-local in the library: copy it here
+    }) {}
+    ~DeviceOpener() {
+        if (th_.joinable()) th_.join();
+        if (ctx_) pgt_close(ctx_);
+    }
+    pgt_ctx *get() {
+        if (th_.joinable()) th_.join();
+        if (!ctx_) die("libpgtwin: " + err_);
+        return ctx_;
+    }
+
+  private:
+    pgt_ctx *ctx_ = nullptr;
+    std::string err_;
+    std::thread th_;
+};
 
 // Window size / step size as fstWindow.cpp:51-64 reads them (atoi); zero, negative or
 // non-numeric values are refused.  The reference only warns for a bad step and then crashes
