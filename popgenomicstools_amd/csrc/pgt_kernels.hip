@@ -311,6 +311,10 @@ struct FstTraits {
     struct Cols { const double *a, *b; };
     static __device__ __forceinline__ Cols cols(const Args &g, int pair) { return {g.cols.a[pair], g.cols.b[pair]}; }
     static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) { return {c.a[i], c.b[i]}; }
+    static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
+                                                     uint64_t) {
+        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
+    }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
                                                   uint64_t lo, uint64_t hi) {
         Row r;
@@ -339,6 +343,33 @@ struct HetTraits {
         const int v = c[i];
         return {(uint32_t)(v >= 0), (uint32_t)(v == 1)};
     }
+    // Ragged site ranges (< 1024 bytes each side): aligned 16-byte loads with the bytes outside
+    // [from,to) forced to "missing" (0x80), instead of one byte per lane and iteration.
+    static __device__ __forceinline__ uint32_t byte_mask(int64_t l, int64_t h) {  // bytes [l,h) of a word
+        l = l < 0 ? 0 : (l > 4 ? 4 : l);
+        h = h < 0 ? 0 : (h > 4 ? 4 : h);
+        if (h <= l) return 0u;
+        const uint32_t ones = (h - l) == 4 ? 0xFFFFFFFFu : ((1u << (8 * (int)(h - l))) - 1u);
+        return ones << (8 * (int)l);
+    }
+    static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
+                                                     uint64_t n_sites) {
+        if (from >= to) return;
+        for (uint64_t base = (from & ~15ull) + 16ull * lane; base < to; base += 16ull * kWave) {
+            if (base + 16 <= n_sites) {  // the column is 16-byte aligned (checked by the API)
+                const uint4 w = *reinterpret_cast<const uint4 *>(c + base);
+                const int64_t l = (int64_t)from - (int64_t)base, h = (int64_t)to - (int64_t)base;
+                const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t m = byte_mask(l - 4 * j, h - 4 * j);
+                    het_count_word((wd[j] & m) | (~m & 0x80808080u), acc.nonmiss, acc.nhet);
+                }
+            } else {  // last, partial 16 bytes of the column
+                for (uint64_t i = base > from ? base : from; i < to && i < base + 16; ++i) node_add(acc, leaf(c, i));
+            }
+        }
+    }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
                                                   uint64_t, uint64_t) {
         Row r;
@@ -366,6 +397,10 @@ struct DxyTraits {
         dxy_acc(v, dxy_site(c.p1[i], c.p2[i], c.n1[i], c.n2[i], c.minind));
         return v;
     }
+    static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
+                                                     uint64_t) {
+        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
+    }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
                                                   uint64_t, uint64_t) {
         Row r;
@@ -387,9 +422,9 @@ struct DxyTraits {
 template <class Tr>
 __device__ __forceinline__ void sum_level(typename Tr::Node &acc, const typename Tr::Cols &c,
                                           const char *tree, const TreeView &tv, int level,
-                                          uint64_t from, uint64_t to, int lane) {
+                                          uint64_t from, uint64_t to, int lane, uint64_t n_sites) {
     if (level == 0) {
-        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, Tr::leaf(c, i));
+        Tr::sum_sites(acc, c, from, to, lane, n_sites);
     } else {
         const typename Tr::Node *nodes = reinterpret_cast<const typename Tr::Node *>(tree + tv.off[level - 1]);
         for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, nodes[i]);
@@ -423,17 +458,17 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
         uint64_t clo = lo, chi = hi;  // current range, in nodes of level k (level 0 = sites)
         for (int k = 0;; ++k) {
             if (k == tv.n_levels) {  // top level: whatever is left
-                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane);
+                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
                 break;
             }
             const uint64_t r = k == 0 ? (uint64_t)Tr::kLeaf : (uint64_t)kRadix;
             const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
             if (ulo >= uhi) {  // no whole parent inside: finish at this level
-                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane);
+                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
                 break;
             }
-            sum_level<Tr>(acc, c, tree, tv, k, clo, ulo * r, lane);  // ragged left  (< r nodes)
-            sum_level<Tr>(acc, c, tree, tv, k, uhi * r, chi, lane);  // ragged right (< r nodes)
+            sum_level<Tr>(acc, c, tree, tv, k, clo, ulo * r, lane, n_sites);  // ragged left  (< r nodes)
+            sum_level<Tr>(acc, c, tree, tv, k, uhi * r, chi, lane, n_sites);  // ragged right (< r nodes)
             clo = ulo;
             chi = uhi;
         }

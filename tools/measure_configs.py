@@ -37,7 +37,9 @@ def timed(ctx, fn, reps=12):
 
 def main():
     dev = torch.device("cuda", 0)
-    n, chroms, W, S = 100_000_000, 20, 50_000, 10_000
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+    big = n > 200_000_000  # at 10^9 sites the 28-pair and host-buffer legs are skipped (memory / time)
+    chroms, W, S = (40 if big else 20), 50_000, 10_000
     ctx = pgt.Context(0)
     gen = torch.Generator(device=dev).manual_seed(7)
     pos, a, b, run_len = bench.synth_columns(n, chroms, 12345, dev)
@@ -50,20 +52,25 @@ def main():
         print(f"| {name} | {bps} | {bm:.4f} | {bps * n / bm / 1e6:.0f} | {bps * n / bm / 1e6 / 80:.1f} | {qm:.4f} | {step:.4f} | {n / step * 1e3:.3e} |")
 
     from popgenomicstools_amd._lib import PGT_STAT_DXY, PGT_STAT_FST, PGT_STAT_HET
-    tree = torch.empty(28 * ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)  # reused by every config
+    n_pairs = 2 if big else 28
+    tree = torch.empty(n_pairs * ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)  # reused by every config
     out = torch.empty(28 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
-    row("2: fstWindow 1e8", 16, timed(ctx, lambda: ctx.fst_reduce_dev(pos, a, b, win, out=out, tree=tree)))
+    ctx.set_max_window(W)
+    row(f"2: fstWindow {n:.0e}", 16, timed(ctx, lambda: ctx.fst_reduce_dev(pos, a, b, win, out=out, tree=tree)))
     p1 = torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 1e6) / 1e6
     p2 = torch.round(torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 1e6) / 1e6
     n1 = torch.randint(0, 21, (n,), generator=gen, device=dev, dtype=torch.int32)
     n2 = torch.randint(0, 21, (n,), generator=gen, device=dev, dtype=torch.int32)
     g1 = (torch.randint(0, 20, (n,), generator=gen, device=dev, dtype=torch.int32) % 4 - 1).to(torch.int8)
     g2 = (torch.randint(0, 20, (n,), generator=gen, device=dev, dtype=torch.int32) % 4 - 1).to(torch.int8)
-    row("3a: dxyWindow alone 1e8", 24, timed(ctx, lambda: ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, 5, win, out=out, tree=tree)))
-    row("3b: hetWindow alone 1e8", 1, timed(ctx, lambda: ctx.het_reduce_dev(pos, g1, win, out=out, tree=tree)))
-    row("3: dxy + het x2 fused 1e8", 26, timed(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)))
+    row(f"3a: dxyWindow alone {n:.0e}", 24, timed(ctx, lambda: ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, 5, win, out=out, tree=tree)))
+    row(f"3b: hetWindow alone {n:.0e}", 1, timed(ctx, lambda: ctx.het_reduce_dev(pos, g1, win, out=out, tree=tree)))
+    row(f"3: dxy + het x2 fused {n:.0e}", 26, timed(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)))
     del p1, p2, n1, n2, g1, g2
-    n_pairs = 28
+    if big:
+        print(f"\n({n:.0e} sites: 28-pair and host-buffer legs skipped)")
+        ctx.close()
+        return
     al = [a] + [a.roll(1000 * (k + 1)) for k in range(n_pairs - 1)]
     bl = [b] + [b.roll(1000 * (k + 1)) for k in range(n_pairs - 1)]
     row("5: fstWindow 28 pairs x 1e8 (one GPU)", 448, timed(ctx, lambda: ctx.fst_reduce_pairs_dev(pos, al, bl, win, out=out, tree=tree), reps=6))
