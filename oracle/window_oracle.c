@@ -601,3 +601,161 @@ int orc_dxy_text_path(const char *maf1, const char *maf2, const char *sizefile, 
     int c1 = fclose(o), c2 = fclose(e);
     return (c1 || c2) ? ORC_EIO : rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * ihsWindow.cpp:123-221 / xpehhWindow.cpp:126-232
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    orc_ext_row *rows;
+    size_t cap, count;
+} ext_sink;
+
+static void ext_print(ext_sink *sk, uint32_t label, uint32_t ws, uint32_t we, uint32_t nbig, uint32_t nsites,
+                      double value, uint32_t position, uint64_t lo, uint64_t hi) {
+    if (sk->count < sk->cap) {
+        orc_ext_row *r = &sk->rows[sk->count];
+        memset(r, 0, sizeof *r);
+        r->label = label; r->start = ws; r->end = we; r->nsites = nsites; r->nbig = nsites ? nbig : 0;
+        r->value = nsites ? value : 0.0; r->position = nsites ? position : 0;
+        r->lo = lo; r->hi = hi;
+    }
+    sk->count++;
+}
+
+int orc_extreme_scan(const uint32_t *chr, const uint32_t *pos, const double *score, size_t n, uint32_t W, int mode,
+                     double cutoff, const uint32_t *run_chr_len, size_t n_runs, orc_ext_row *out, size_t cap,
+                     size_t *n_out) {
+    if (!n_out || W < 1 || mode < ORC_EXT_IHS || mode > ORC_EXT_XP_MIN) return ORC_EARG;
+    if (n == 0) return ORC_EDOMAIN; /* the reference prints one window with an empty name */
+    ext_sink sk = {out, cap, 0};
+    uint32_t run = 0, ws = 1, we = ws + (W - 1), nsites = 0, nbig = 0, best_pos = 0;
+    double best_key = 0, best_val = 0;
+    uint32_t chrlen = (run_chr_len && n_runs) ? run_chr_len[0] : 0; /* ihsWindow.cpp:154-157: first window NOT clamped */
+    uint64_t lo = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int newchr = i > 0 && chr[i] != chr[i - 1];
+        if (chrlen && pos[i] > chrlen) return ORC_EDOMAIN; /* the reference would loop forever (:184) */
+        if (newchr) { /* :160-175 */
+            ext_print(&sk, run, ws, we, nbig, nsites, best_val, best_pos, lo, i);
+            while (we < chrlen) {
+                ws = we + 1; we = ws + (W - 1);
+                if (chrlen && we > chrlen) we = chrlen;
+                ext_print(&sk, run, ws, we, 0, 0, 0, 0, i, i);
+            }
+            ++run;
+            nsites = 0; lo = i;
+            chrlen = (run_chr_len && run < n_runs) ? run_chr_len[run] : 0;
+            ws = 1; we = ws + (W - 1);
+            if (chrlen && we > chrlen) we = chrlen;
+        } else if (pos[i] >= we) { /* :176-190 */
+            ext_print(&sk, run, ws, we, nbig, nsites, best_val, best_pos, lo, i);
+            ws = we + 1; we = ws + (W - 1);
+            if (chrlen && we > chrlen) we = chrlen;
+            nsites = 0; lo = i;
+            while (pos[i] > we) {
+                ext_print(&sk, run, ws, we, 0, 0, 0, 0, i, i);
+                ws = we + 1; we = ws + (W - 1);
+                if (chrlen && we > chrlen) we = chrlen;
+            }
+        }
+        const double s = score[i];
+        const double key = mode == ORC_EXT_IHS ? fabs(s) : (mode == ORC_EXT_XP_MAX ? s : -s);
+        const double thr = mode == ORC_EXT_XP_MIN ? -cutoff : cutoff;
+        if (nsites == 0) { nbig = 0; best_key = key; best_val = s; best_pos = pos[i]; } /* :194-197 */
+        if (key > best_key) { best_key = key; best_val = s; best_pos = pos[i]; }         /* :199-201 */
+        if (key > thr) ++nbig;                                                             /* :203-205 */
+        ++nsites;
+    }
+    ext_print(&sk, run, ws, we, nbig, nsites, best_val, best_pos, lo, n); /* :212 */
+    while (we < chrlen) { /* :213-218 */
+        ws = we + 1; we = ws + (W - 1);
+        if (we > chrlen) we = chrlen;
+        ext_print(&sk, run, ws, we, 0, 0, 0, 0, n, n);
+    }
+    *n_out = sk.count;
+    return sk.count > cap ? ORC_ECAP : ORC_OK;
+}
+
+/* selscan *.norm text: "<chr>_<...> pos f0 f1 ..." ; score = field `score_field` after pos
+ * (ihs: 4 -> sitevec[4], xpehh: 6 -> sitevec[6]); the chromosome is the locus id up to the first '_'
+ * (ihsWindow.cpp:82-93). */
+static int ext_text(const char *in, int skip_header, int score_field, uint32_t W, int mode, double cutoff,
+                    const char *chrlen_path, const char *out_path) {
+    FILE *f = fopen(in, "r");
+    if (!f) return ORC_EIO;
+    table t;
+    memset(&t, 0, sizeof t);
+    char *line = NULL;
+    size_t lcap = 0;
+    int rc = ORC_OK;
+    if (skip_header && getline(&line, &lcap, f) < 0) { fclose(f); free(line); return ORC_EDOMAIN; }
+    while (getline(&line, &lcap, f) >= 0) {
+        const char *p = skip_ws(line);
+        if (*p == '\n' || *p == 0) continue;
+        const char *e = skip_tok(p);
+        const char *us = memchr(p, '_', (size_t)(e - p));
+        if (table_grow(&t) || table_run(&t, p, (size_t)((us ? us : e) - p))) { rc = ORC_EIO; break; }
+        char *q;
+        t.chr[t.n] = (uint32_t)(t.n_runs - 1);
+        t.pos[t.n] = (uint32_t)strtoul(e, &q, 10);
+        double v = 0;
+        for (int k = 0; k <= score_field; ++k) v = strtod(q, &q);
+        t.x[t.n] = v;
+        t.n++;
+    }
+    free(line);
+    fclose(f);
+    uint32_t *len = NULL;
+    orc_ext_row *rows = NULL;
+    if (rc == ORC_OK && chrlen_path && *chrlen_path) {
+        len = calloc(t.n_runs ? t.n_runs : 1, sizeof *len);
+        FILE *cf = fopen(chrlen_path, "r");
+        if (!cf || !len) { if (cf) fclose(cf); rc = ORC_EIO; }
+        else {
+            char name[4096];
+            unsigned L;
+            /* std::map::insert keeps the first entry of a name; a run's length is looked up by name */
+            while (fscanf(cf, "%4095s %u", name, &L) == 2)
+                for (size_t r = 0; r < t.n_runs; ++r)
+                    if (!strcmp(name, t.run_name[r]) && !len[r]) len[r] = L;
+            fclose(cf);
+        }
+    }
+    if (rc == ORC_OK) {
+        size_t cap = 16, nr = 0;
+        for (;;) {
+            free(rows);
+            rows = malloc(cap * sizeof *rows);
+            rc = orc_extreme_scan(t.chr, t.pos, t.x, t.n, W, mode, cutoff, len, len ? t.n_runs : 0, rows, cap, &nr);
+            if (rc != ORC_ECAP) break;
+            cap = nr;
+        }
+        if (rc == ORC_OK) {
+            FILE *o = fopen(out_path, "w");
+            if (!o) rc = ORC_EIO;
+            else {
+                for (size_t i = 0; i < nr; ++i) {
+                    fprintf(o, "%s\t%u\t%u\t", t.run_name[rows[i].label], rows[i].start, rows[i].end);
+                    if (rows[i].nsites) /* ihsWindow.cpp:104-107 */
+                        fprintf(o, "%g\t%u\t%g\t%u\n", rows[i].value, rows[i].position,
+                                (double)(int)rows[i].nbig / rows[i].nsites, rows[i].nsites);
+                    else
+                        fprintf(o, "NA\tNA\tNA\t0\n");
+                }
+                if (fclose(o)) rc = ORC_EIO;
+            }
+        }
+    }
+    free(rows);
+    free(len);
+    table_free(&t);
+    return rc;
+}
+
+int orc_ihs_text_path(const char *in, uint32_t W, double cutoff, const char *chrlen_path, const char *out_path) {
+    return ext_text(in, 0, 4, W, ORC_EXT_IHS, cutoff, chrlen_path, out_path);
+}
+
+int orc_xpehh_text_path(const char *in, double cutoff, uint32_t W, const char *chrlen_path, const char *out_path) {
+    return ext_text(in, 1, 6, W, cutoff < 0 ? ORC_EXT_XP_MIN : ORC_EXT_XP_MAX, cutoff, chrlen_path, out_path);
+}

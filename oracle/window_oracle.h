@@ -85,6 +85,28 @@ void orc_wcfst_site(double f1, double f2, double n1, double n2, double *a, doubl
 void orc_wcfst_columns(const double *f1, const double *f2, size_t n, double n1, double n2,
                        double *a, double *ab);
 
+/* ---- ihsWindow / xpehhWindow: non-overlapping bp windows, extreme score -------
+ * Restates ihsWindow.cpp:123-221 and xpehhWindow.cpp:126-232 (one loop, two scoring rules).
+ * Pinned byte-for-byte against oracle/_ref/{ihsWindow,xpehhWindow} (tests/golden/ref_extreme.json). */
+enum { ORC_EXT_IHS = 0,      /* key |s|, count |s| > cutoff            (ihsWindow.cpp:193-205)   */
+       ORC_EXT_XP_MAX = 1,   /* key s,   count s > cutoff (cutoff >= 0) (xpehhWindow.cpp:213-216) */
+       ORC_EXT_XP_MIN = 2 }; /* key -s,  count s < cutoff (cutoff < 0)  (xpehhWindow.cpp:210-212) */
+typedef struct {
+    uint32_t label;   /* chromosome run */
+    uint32_t start, end;
+    uint32_t nsites, nbig;
+    uint32_t position; /* of the extreme score; 0 when nsites == 0 */
+    uint64_t lo, hi;   /* site range of the window */
+    double value;      /* the extreme score itself (signed); 0 when nsites == 0 */
+} orc_ext_row;
+/* run_chr_len[r] = -chrlen length of run r's chromosome, 0 = not given (ihsWindow.cpp:156,172-174). */
+int orc_extreme_scan(const uint32_t *chr, const uint32_t *pos, const double *score, size_t n, uint32_t W,
+                     int mode, double cutoff, const uint32_t *run_chr_len, size_t n_runs,
+                     orc_ext_row *out, size_t cap, size_t *n_out);
+/* Text front ends with the tools' argv meaning (chrlen_path may be NULL/""), TSV to out_path. */
+int orc_ihs_text_path(const char *in, uint32_t W, double cutoff, const char *chrlen_path, const char *out_path);
+int orc_xpehh_text_path(const char *in, double cutoff, uint32_t W, const char *chrlen_path, const char *out_path);
+
 /* Text front ends: same argv meaning and TSV as the reference tools, written to `out`
  * (and `err` for the dxy genome-wide line, dxyWindow.cpp:429-433).  Used for byte parity with
  * oracle/_ref and as the "port" CPU baseline when oracle/_ref is absent. */

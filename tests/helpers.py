@@ -69,3 +69,17 @@ def assert_rows_match_tsv(names, win, rows, stat_field, count_field, tsv_rows, w
         got = float(r[stat_field])
         assert abs(got - ref) <= 5.1e-6 * abs(ref) + 1e-12, (got, ref)
         assert str(int(r[count_field])) == t[k + 1]
+
+
+def extreme_case_args(case, tmp_path):
+    """Materialise a ref_extreme.json case: returns (in_path, W, cutoff, chrlen_path or None)."""
+    paths = {}
+    for name, text in case["files"].items():
+        p = tmp_path / name
+        p.write_text(text)
+        paths[name] = str(p)
+    a = case["args"]
+    W = int(a[a.index("-winsize") + 1])
+    chrlen = paths[a[a.index("-chrlen") + 1][1:]] if "-chrlen" in a else None
+    cutoff = float(a[a.index("-cutoff") + 1]) if case["tool"] == "ihsWindow" else float(a[1])
+    return paths["in.norm"], W, cutoff, chrlen

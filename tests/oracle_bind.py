@@ -140,3 +140,47 @@ def ref_binary(tool):
     """Path of the compiled UNMODIFIED reference tool (oracle/_ref), or None if absent."""
     p = os.path.join(REF_DIR, tool)
     return p if os.path.exists(p) and os.access(p, os.X_OK) else None
+
+
+EXT_ROW = np.dtype([("label", "<u4"), ("start", "<u4"), ("end", "<u4"), ("nsites", "<u4"), ("nbig", "<u4"),
+                    ("position", "<u4"), ("lo", "<u8"), ("hi", "<u8"), ("value", "<f8")])
+assert EXT_ROW.itemsize == 48
+
+
+def _extreme_scan(self, chr_ids, pos, score, W, mode, cutoff, run_chr_len=None):
+    c, p = _u32(chr_ids), _u32(pos)
+    s = np.ascontiguousarray(score, dtype=np.float64)
+    rl = _u32(run_chr_len) if run_chr_len is not None else None
+    f = self.lib.orc_extreme_scan
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_double, C.c_void_p,
+                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    cap = 64
+    while True:
+        out = np.zeros(cap, dtype=EXT_ROW)
+        n_out = C.c_size_t(0)
+        rc = f(c.ctypes.data, p.ctypes.data, s.ctypes.data, p.size, W, mode, float(cutoff),
+               rl.ctypes.data if rl is not None else None, rl.size if rl is not None else 0, out.ctypes.data, cap,
+               C.byref(n_out))
+        if rc == 2:
+            cap = n_out.value
+            continue
+        if rc != 0:
+            raise RuntimeError(f"oracle error {rc}")
+        return out[: n_out.value].copy()
+
+
+def _ihs_text(self, path, W, cutoff, chrlen_path, out_path):
+    f = self.lib.orc_ihs_text_path
+    f.argtypes = [C.c_char_p, C.c_uint32, C.c_double, C.c_char_p, C.c_char_p]
+    return f(path.encode(), W, float(cutoff), (chrlen_path or "").encode(), out_path.encode())
+
+
+def _xpehh_text(self, path, cutoff, W, chrlen_path, out_path):
+    f = self.lib.orc_xpehh_text_path
+    f.argtypes = [C.c_char_p, C.c_double, C.c_uint32, C.c_char_p, C.c_char_p]
+    return f(path.encode(), float(cutoff), W, (chrlen_path or "").encode(), out_path.encode())
+
+
+Oracle.extreme_scan = _extreme_scan
+Oracle.ihs_text = _ihs_text
+Oracle.xpehh_text = _xpehh_text

@@ -112,3 +112,18 @@ def test_live_reference_fuzz(oracle, tmp_path):
         ref = subprocess.run([oracle_bind.ref_binary(tool), str(src), str(W), str(S)], capture_output=True, timeout=10)
         rc, out = _run_text(oracle, tool, text, W, S, tmp_path)
         assert rc == 0 and out.encode() == ref.stdout
+
+
+def test_extreme_tools_byte_identical(oracle, tmp_path):
+    """ihsWindow / xpehhWindow restatement against the reference binaries' stdout."""
+    cases = helpers.load_golden("ref_extreme.json")["cases"]
+    assert len(cases) >= 100
+    for c in cases:
+        src, W, cutoff, chrlen = helpers.extreme_case_args(c, tmp_path)
+        out = tmp_path / "o.txt"
+        if c["tool"] == "ihsWindow":
+            rc = oracle.ihs_text(src, W, cutoff, chrlen, str(out))
+        else:
+            rc = oracle.xpehh_text(src, cutoff, W, chrlen, str(out))
+        assert rc == 0 and c["rc"] == 0
+        assert out.read_text() == c["stdout"], c["args"]
