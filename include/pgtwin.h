@@ -117,7 +117,7 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).  `tree` is caller
  * workspace of at least pgt_tree_bytes(stat, n) bytes, 256-byte aligned: it receives the
  * radix-64 range tree and may be reused by later calls. */
-enum { PGT_STAT_FST = 0, PGT_STAT_HET = 1, PGT_STAT_DXY = 2 };
+enum { PGT_STAT_FST = 0, PGT_STAT_HET = 1, PGT_STAT_DXY = 2, PGT_STAT_EXT = 3 };
 size_t pgt_tree_bytes(int stat, uint64_t n_sites);
 
 int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b,
@@ -166,6 +166,35 @@ size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites);
 int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
                           uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
                           void *tree, size_t tree_bytes, void *stream);
+
+/* ---- ihsWindow / xpehhWindow: extreme score in non-overlapping bp windows ---- */
+/* Replaces the window bookkeeping and per-window scan of ihsWindow.cpp:123-221 and
+ * xpehhWindow.cpp:126-232: the most extreme score of the window (first occurrence on ties), its
+ * position, and the number of scores beyond the cutoff. */
+enum {
+    PGT_EXT_IHS = 0,    /* extreme = largest |s|, count |s| > cutoff           (ihsWindow.cpp:193-205)   */
+    PGT_EXT_XP_MAX = 1, /* extreme = largest s,   count s > cutoff (cutoff>=0) (xpehhWindow.cpp:213-216) */
+    PGT_EXT_XP_MIN = 2  /* extreme = smallest s,  count s < cutoff (cutoff<0)  (xpehhWindow.cpp:210-212) */
+};
+typedef struct { /* ihsWindow.cpp:101-110 row: chr start end score position proportion nsites */
+    uint32_t start, end, nsites, nbig;
+    uint32_t position, pad_; /* position of the extreme score; 0 when nsites == 0 (the tool prints NA) */
+    double value;            /* the extreme score (signed) */
+} pgt_ext_row;
+/* The tools' window rules applied site by site on the host (they are history dependent: a site at
+ * pos >= window end opens the next window, ihsWindow.cpp:176-190): fixed bp windows [1,W],[W+1,2W],..
+ * per chromosome, clamped to chr_len[r] where given (0 = not given; chr_len may be NULL), empty
+ * windows included, trailing windows up to the chromosome length.  O(n).  Rows carry
+ * PGT_WIN_COORDS.  PGT_EDOMAIN for n == 0 or a position beyond a given chromosome length (the
+ * reference prints a nameless window / loops forever there). */
+int pgt_build_windows_extreme(const uint32_t *pos, const uint64_t *run_len, const uint32_t *chr_len,
+                              size_t n_runs, uint32_t W, pgt_win *out, size_t cap, size_t *n_out);
+int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode,
+                       double cutoff, const pgt_win *win, uint64_t n_win, pgt_ext_row *out);
+/* device-resident form; tree: pgt_tree_bytes(PGT_STAT_EXT, n) bytes */
+int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode,
+                           double cutoff, const pgt_win *win, uint64_t n_win, pgt_ext_row *out,
+                           void *tree, size_t tree_bytes, void *stream);
 
 /* ---- performance hint ------------------------------------------------------------------- */
 /* Longest window (in sites) the following *_dev calls will be asked for; 0 (the default) = unknown.

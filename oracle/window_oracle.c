@@ -634,7 +634,10 @@ int orc_extreme_scan(const uint32_t *chr, const uint32_t *pos, const double *sco
     uint64_t lo = 0;
     for (size_t i = 0; i < n; ++i) {
         const int newchr = i > 0 && chr[i] != chr[i - 1];
-        if (chrlen && pos[i] > chrlen) return ORC_EDOMAIN; /* the reference would loop forever (:184) */
+        {   /* a position beyond its chromosome's given length makes the reference loop forever (:184) */
+            const uint32_t own_len = newchr ? ((run_chr_len && run + 1 < n_runs) ? run_chr_len[run + 1] : 0) : chrlen;
+            if (own_len && pos[i] > own_len) return ORC_EDOMAIN;
+        }
         if (newchr) { /* :160-175 */
             ext_print(&sk, run, ws, we, nbig, nsites, best_val, best_pos, lo, i);
             while (we < chrlen) {

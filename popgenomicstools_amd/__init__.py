@@ -11,13 +11,16 @@ Layout
 from .window_scan import (  # noqa: F401
     Context,
     build_windows_bp,
+    build_windows_extreme,
     build_windows_sites,
     dxy_window,
     fst_window,
     het_window,
+    ihs_window,
     plan_shards,
     run_lengths,
+    xpehh_window,
 )
 
 __all__ = ["Context", "build_windows_sites", "build_windows_bp", "fst_window", "het_window",
-           "dxy_window", "plan_shards", "run_lengths"]
+           "dxy_window", "ihs_window", "xpehh_window", "build_windows_extreme", "plan_shards", "run_lengths"]

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_PKG, "libpgtwin.so")
 
 PGT_OK, PGT_EARG, PGT_ECAP, PGT_EDEVICE, PGT_EDOMAIN, PGT_ENOMEM = range(6)
 PGT_WIN_COORDS = 1
-PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY = 0, 1, 2
+PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY, PGT_STAT_EXT = 0, 1, 2, 3
+PGT_EXT_IHS, PGT_EXT_XP_MAX, PGT_EXT_XP_MIN = 0, 1, 2
 
 # numpy views of the C structs (layout asserted against ctypes below)
 WIN_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8"), ("label_run", "<u4"), ("flags", "<u4"),
@@ -27,15 +28,19 @@ HET_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("mid", "<u4"), ("no
 DXY_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("neff", "<u4"), ("nskip", "<u4"),
                           ("sum", "<f8")])
 DXY_TOTAL_DTYPE = np.dtype([("sum", "<f8"), ("neff", "<u8"), ("nskip", "<u8")])
+EXT_ROW_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("nsites", "<u4"), ("nbig", "<u4"),
+                          ("position", "<u4"), ("pad_", "<u4"), ("value", "<f8")])
 SHARD_DTYPE = np.dtype([("win_begin", "<u8"), ("win_end", "<u8"), ("site_lo", "<u8"), ("site_hi", "<u8")])
 
 assert WIN_DTYPE.itemsize == 32 and FST_ROW_DTYPE.itemsize == 40 and HET_ROW_DTYPE.itemsize == 32
+assert EXT_ROW_DTYPE.itemsize == 32
 assert DXY_ROW_DTYPE.itemsize == 24 and DXY_TOTAL_DTYPE.itemsize == 24 and SHARD_DTYPE.itemsize == 32
 
 # every symbol include/pgtwin.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
     "pgt_open", "pgt_close", "pgt_last_error", "pgt_abi_version",
-    "pgt_build_windows_sites", "pgt_build_windows_bp",
+    "pgt_build_windows_sites", "pgt_build_windows_bp", "pgt_build_windows_extreme",
+    "pgt_extreme_reduce", "pgt_extreme_reduce_dev",
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
@@ -78,6 +83,9 @@ def load() -> C.CDLL:
     lib.pgt_abi_version.restype = i32
     lib.pgt_build_windows_sites.argtypes = [vp, sz, u32, u32, vp, sz, C.POINTER(sz)]
     lib.pgt_build_windows_bp.argtypes = [vp, vp, vp, sz, u32, u32, vp, sz, C.POINTER(sz)]
+    lib.pgt_build_windows_extreme.argtypes = [vp, vp, vp, sz, u32, vp, sz, C.POINTER(sz)]
+    lib.pgt_extreme_reduce.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp]
+    lib.pgt_extreme_reduce_dev.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp, vp, sz, vp]
     lib.pgt_fst_reduce.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp]
     lib.pgt_het_reduce.argtypes = [vp, vp, vp, u64, vp, u64, vp]
     lib.pgt_dxy_reduce.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp]

@@ -19,7 +19,7 @@ BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libpgtwin.so")
 
 LIB_SOURCES = ["pgt_kernels.hip", "pgt_af_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
-HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow"]
+HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow", "ihsWindow", "xpehhWindow"]
 
 
 def _hipcc() -> str:
@@ -57,7 +57,7 @@ def build_hosts(force: bool = False) -> list[str]:
     """The retained C++ hosts: same argv and TSV as the reference tools, reduction in libpgtwin."""
     os.makedirs(BIN, exist_ok=True)
     out = []
-    common = [os.path.join(HOST, "host_common.h"), os.path.join(ROOT, "include", "pgtwin.h"), LIB]
+    common = [os.path.join(HOST, "host_common.h"), os.path.join(HOST, "extreme_common.h"), os.path.join(ROOT, "include", "pgtwin.h"), LIB]
     for tool in HOST_TOOLS:
         src = os.path.join(HOST, tool + "_main.cpp")
         if not os.path.exists(src):

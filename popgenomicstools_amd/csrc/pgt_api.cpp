@@ -152,7 +152,7 @@ const char *pgt_last_error(const pgt_ctx *ctx) {
 }
 
 size_t pgt_tree_bytes(int stat, uint64_t n_sites) {
-    if (stat < PGT_STAT_FST || stat > PGT_STAT_DXY) return 0;
+    if (stat < PGT_STAT_FST || stat > PGT_STAT_EXT) return 0;
     return tree_layout(stat, n_sites).bytes;
 }
 
@@ -271,7 +271,45 @@ int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const
                          ctx->max_window);
 }
 
+int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
+                           const pgt_win *win, uint64_t n_win, pgt_ext_row *out, void *tree, size_t tree_bytes,
+                           void *stream) {
+    if (int rc = use_device(ctx)) return rc;
+    if (!score || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    if (mode < PGT_EXT_IHS || mode > PGT_EXT_XP_MIN) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: unknown mode");
+    if (!aligned16(score)) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: score column must be 16-byte aligned");
+    if (n >= 0xFFFFFFFFull) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: at most 2^32-2 sites per call");
+    if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_EXT, n))
+        return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: tree workspace too small or misaligned");
+    const EvSet e = events_for(ctx);
+    return launch_ext(pos, score, n, mode, cutoff, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
+                      ctx->max_window);
+}
+
 /* ---------------- host-buffer entry points ---------------- */
+
+int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
+                       const pgt_win *win, uint64_t n_win, pgt_ext_row *out) {
+    if (int rc = use_device(ctx)) return rc;
+    if ((n && (!pos || !score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
+    DevBuf dpos, ds, dwin, dout, dtree;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = ds.upload(ctx, score, n * sizeof(double), "upload scores")) return rc;
+    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
+    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_ext_row), "alloc rows")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_EXT, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_extreme_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(ds.p), n, mode, cutoff,
+                                        static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_ext_row *>(dout.p), dtree.p,
+                                        tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "extreme kernels")) return rc;
+    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_ext_row), hipMemcpyDeviceToHost), "download rows");
+    return PGT_OK;
+}
+
 
 int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
                    const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {

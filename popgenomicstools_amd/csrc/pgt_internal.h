@@ -119,6 +119,9 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
                    pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, void *stream,
                    void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 
+int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
+               uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
+               void *ev_query1, std::string *err, uint64_t max_window);
 int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops,
                   uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);

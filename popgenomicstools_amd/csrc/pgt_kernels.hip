@@ -37,7 +37,31 @@ struct alignas(16) NodeFst { double x, y; };
 struct alignas(8) NodeHet { uint32_t nonmiss, nhet; };
 struct alignas(16) NodeDxy { double s; uint32_t neff, nskip; };
 
+// ihsWindow / xpehhWindow: running extreme (key, first site index attaining it) and the count beyond
+// the cutoff.  The combine is commutative and associative (ties go to the smaller site index, i.e. the
+// first occurrence, as the strict `>` of ihsWindow.cpp:199 gives), so any reduction tree is exact.
+struct alignas(16) NodeExt { double key; uint32_t idx, count; };
+
+template <class N> __device__ __forceinline__ N node_identity() { return N{}; }
+template <> __device__ __forceinline__ NodeExt node_identity<NodeExt>() {
+    return NodeExt{-__builtin_huge_val(), 0xFFFFFFFFu, 0u};
+}
+
 __device__ __forceinline__ void node_add(NodeFst &a, const NodeFst &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void node_add(NodeExt &a, const NodeExt &b) {
+    a.count += b.count;
+    if (b.key > a.key || (b.key == a.key && b.idx < a.idx)) { a.key = b.key; a.idx = b.idx; }
+}
+__device__ __forceinline__ NodeExt node_wave_sum(NodeExt v) {
+    NodeExt o;
+    o = {dpp_f64<kDppQuadXor1>(v.key), dpp_u32<kDppQuadXor1>(v.idx), dpp_u32<kDppQuadXor1>(v.count)}; node_add(v, o);
+    o = {dpp_f64<kDppQuadXor2>(v.key), dpp_u32<kDppQuadXor2>(v.idx), dpp_u32<kDppQuadXor2>(v.count)}; node_add(v, o);
+    o = {dpp_f64<kDppRowHalfMirror>(v.key), dpp_u32<kDppRowHalfMirror>(v.idx), dpp_u32<kDppRowHalfMirror>(v.count)}; node_add(v, o);
+    o = {dpp_f64<kDppRowMirror>(v.key), dpp_u32<kDppRowMirror>(v.idx), dpp_u32<kDppRowMirror>(v.count)}; node_add(v, o);
+    o = {__shfl_xor(v.key, 16, kWave), (uint32_t)__shfl_xor((int)v.idx, 16, kWave), (uint32_t)__shfl_xor((int)v.count, 16, kWave)}; node_add(v, o);
+    o = {__shfl_xor(v.key, 32, kWave), (uint32_t)__shfl_xor((int)v.idx, 32, kWave), (uint32_t)__shfl_xor((int)v.count, 32, kWave)}; node_add(v, o);
+    return v;
+}
 __device__ __forceinline__ void node_add(NodeHet &a, const NodeHet &b) { a.nonmiss += b.nonmiss; a.nhet += b.nhet; }
 __device__ __forceinline__ void node_add(NodeDxy &a, const NodeDxy &b) { a.s += b.s; a.neff += b.neff; a.nskip += b.nskip; }
 __device__ __forceinline__ NodeFst node_wave_sum(NodeFst v) { return {wave_sum(v.x), wave_sum(v.y)}; }
@@ -280,6 +304,13 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
 }
 
 // ------------------------------------------------------------------------------------------
+// BUILD, extreme score (ihsWindow / xpehhWindow): level-1 {key max, first index, count beyond the
+// cutoff} per 128 sites, level-2 per 8192 sites.                                  8 B/site read.
+// ------------------------------------------------------------------------------------------
+struct ExtBuildArgs { const double *s; int mode; double thr; };
+__global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv);
+
+// ------------------------------------------------------------------------------------------
 // Upper levels (only exist when level 2 has more than 64 nodes): parent = Σ of 64 children.
 // ------------------------------------------------------------------------------------------
 template <class Node>
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(256) void tree_up_kernel(TreeView tv, int child_lev
     Node *__restrict__ parent = reinterpret_cast<Node *>(tree + tv.off[child_level + 1]);
     for (uint64_t p = wave0; p < n_parent; p += n_waves) {
         const uint64_t i = p * kRadix + lane;
-        Node v{};
+        Node v = node_identity<Node>();
         if (i < n_child) v = child[i];
         v = node_wave_sum(v);
         if (lane == 0) parent[p] = v;
@@ -316,7 +347,7 @@ struct FstTraits {
         for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
     }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
-                                                  uint64_t lo, uint64_t hi) {
+                                                  uint64_t lo, uint64_t hi, const Cols &, const uint32_t *) {
         Row r;
         r.start = start;
         r.end = end;
@@ -371,7 +402,7 @@ struct HetTraits {
         }
     }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
-                                                  uint64_t, uint64_t) {
+                                                  uint64_t, uint64_t, const Cols &, const uint32_t *) {
         Row r;
         r.start = start;
         r.end = end;
@@ -402,7 +433,7 @@ struct DxyTraits {
         for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
     }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
-                                                  uint64_t, uint64_t) {
+                                                  uint64_t, uint64_t, const Cols &, const uint32_t *) {
         Row r;
         r.start = start;
         r.end = end;
@@ -418,6 +449,89 @@ struct DxyTraits {
         tot->nskip = t.nskip;
     }
 };
+
+struct ExtTraits {
+    using Node = NodeExt;
+    using Row = pgt_ext_row;
+    static constexpr int kLeaf = kLeafF64;
+    struct Args { const double *s; int mode; double thr; };
+    using Cols = Args;
+    static __device__ __forceinline__ Cols cols(const Args &g, int) { return g; }
+    static __device__ __forceinline__ double key_of(double s, int mode) {
+        return mode == PGT_EXT_IHS ? fabs(s) : (mode == PGT_EXT_XP_MAX ? s : -s);
+    }
+    static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) {
+        const double k = key_of(c.s[i], c.mode);
+        return {k, (uint32_t)i, (uint32_t)(k > c.thr)};  // ihsWindow.cpp:203, xpehhWindow.cpp:212,215
+    }
+    static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
+                                                     uint64_t) {
+        for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
+    }
+    static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end, uint64_t lo,
+                                                  uint64_t hi, const Cols &c, const uint32_t *pos) {
+        Row r;
+        r.start = start;
+        r.end = end;
+        r.nsites = (uint32_t)(hi - lo);
+        r.nbig = t.count;
+        r.pad_ = 0;
+        const bool any = hi > lo && t.idx != 0xFFFFFFFFu;
+        r.position = any ? pos[t.idx] : 0u;   // maxihs[2], ihsWindow.cpp:98
+        r.value = any ? c.s[t.idx] : 0.0;     // maxihs[1]: the signed score itself
+        *out = r;
+    }
+    static __device__ __forceinline__ void store_total(pgt_dxy_total *, const Node &) {}
+};
+
+__global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    NodeExt *__restrict__ l1 = reinterpret_cast<NodeExt *>(tv.base + tv.off[0]);
+    NodeExt *__restrict__ l2 = reinterpret_cast<NodeExt *>(tv.base + tv.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+    auto site = [&](double s, uint64_t i) {
+        const double k = ExtTraits::key_of(s, g.mode);
+        return NodeExt{k, (uint32_t)i, (uint32_t)(k > g.thr)};
+    };
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        NodeExt keep = node_identity<NodeExt>();
+        if (base + kTile2 <= n) {
+            const double2 *__restrict__ ps = reinterpret_cast<const double2 *>(g.s + base);
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += 8) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = load16<true>(ps + (j + u) * kWave + lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint64_t i0 = base + (uint64_t)(j + u) * kLeafF64 + 2 * lane;
+                    NodeExt a = site(v[u].x, i0);
+                    node_add(a, site(v[u].y, i0 + 1));
+                    a = node_wave_sum(a);
+                    if (lane == j + u) keep = a;
+                }
+            }
+        } else {  // last, partial level-2 tile
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t tile0 = base + (uint64_t)j * kLeafF64;
+                if (tile0 >= n) break;  // wave-uniform
+                NodeExt a = node_identity<NodeExt>();
+                for (int q = 0; q < 2; ++q) {
+                    const uint64_t i = tile0 + 2 * lane + q;
+                    if (i < n) node_add(a, site(g.s[i], i));
+                }
+                a = node_wave_sum(a);
+                if (lane == j) keep = a;
+            }
+        }
+        l1[t * kRadix + lane] = keep;
+        const NodeExt tot = node_wave_sum(keep);
+        if (lane == 0) l2[t] = tot;
+    }
+}
 
 template <class Tr>
 __device__ __forceinline__ void sum_level(typename Tr::Node &acc, const typename Tr::Cols &c,
@@ -454,7 +568,7 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
         // clamp to the columns so that a corrupt table can never fault the GPU
         const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
         const uint64_t lo = wd.lo < hi ? wd.lo : hi;
-        typename Tr::Node acc{};
+        typename Tr::Node acc = node_identity<typename Tr::Node>();
         uint64_t clo = lo, chi = hi;  // current range, in nodes of level k (level 0 = sites)
         for (int k = 0;; ++k) {
             if (k == tv.n_levels) {  // top level: whatever is left
@@ -482,7 +596,7 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
                     start = hi > lo ? pos[lo] : 0u;
                     end = hi > lo ? pos[hi - 1] : 0u;
                 }
-                Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi);
+                Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
             }
         }
     }
@@ -673,6 +787,30 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
         hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
                            win, n_win, out, n, tot);
         if (int rc = hip_fail(hipGetLastError(), "query_kernel<dxy>", err)) return rc;
+    }
+    return record(ev_query1, s, err);
+}
+
+int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
+               uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
+               void *ev_query1, std::string *err, uint64_t max_window) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TreeLayout tl = tree_layout(PGT_STAT_EXT, n);
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_EXT, max_window));
+    const double thr = mode == PGT_EXT_XP_MIN ? -cutoff : cutoff;  // s < cutoff  <=>  -s > -cutoff
+    if (int rc = record(ev_build0, s, err)) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(ext_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s,
+                           ExtBuildArgs{score, mode, thr}, n, tl.count[1], tv);
+        if (int rc = hip_fail(hipGetLastError(), "ext_build_kernel", err)) return rc;
+        if (int rc = launch_upper<NodeExt>(tl, tv, 1, s, err)) return rc;
+    }
+    if (int rc = record(ev_build1, s, err)) return rc;
+    if (n_win > 0) {
+        ExtTraits::Args args{score, mode, thr};
+        hipLaunchKernelGGL(query_kernel<ExtTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win, n_win,
+                           out, n, (pgt_dxy_total *)nullptr);
+        if (int rc = hip_fail(hipGetLastError(), "query_kernel<ext>", err)) return rc;
     }
     return record(ev_query1, s, err);
 }

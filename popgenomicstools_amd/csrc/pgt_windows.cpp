@@ -169,6 +169,67 @@ extern "C" int pgt_build_windows_bp(const uint32_t *pos, const uint64_t *run_len
     return PGT_OK;
 }
 
+// ihsWindow.cpp:147-218 / xpehhWindow.cpp:158-229: unlike the sliding tools, window membership here
+// depends on the order of events (a site with pos >= winend opens the next window and then sits in
+// it even if pos == its end), so the table is produced by running the tool's own loop over the
+// positions — integer compares only, O(n).
+extern "C" int pgt_build_windows_extreme(const uint32_t *pos, const uint64_t *run_len, const uint32_t *chr_len,
+                                         size_t n_runs, uint32_t W, pgt_win *out, size_t cap, size_t *n_out) {
+    if (!n_out || (n_runs && (!run_len || !pos))) return fail(PGT_EARG, "pgt_build_windows_extreme: NULL argument");
+    if (W < 1) return fail(PGT_EARG, "Window size must be a positive integer");
+    if (n_runs == 0) return fail(PGT_EDOMAIN, "pgt_build_windows_extreme: no sites");
+    size_t count = 0;
+    auto emit = [&](uint64_t lo, uint64_t hi, uint32_t label, uint32_t ws, uint32_t we) {
+        if (out && count < cap) {
+            pgt_win w;
+            w.lo = lo; w.hi = hi; w.label_run = label; w.flags = PGT_WIN_COORDS; w.start = ws; w.end = we;
+            out[count] = w;
+        }
+        ++count;
+    };
+    uint64_t i = 0;
+    uint32_t ws = 1, we = ws + (W - 1);  // the first window of the first chromosome is not clamped (:133-134,154-157)
+    auto advance = [&](uint32_t len) {
+        ws = we + 1;
+        we = ws + (W - 1);
+        if (len && we > len) we = len;
+    };
+    for (size_t r = 0; r < n_runs; ++r) {
+        if (run_len[r] == 0) return fail(PGT_EARG, "pgt_build_windows_extreme: empty chromosome run");
+        const uint32_t len = chr_len ? chr_len[r] : 0;
+        if (r > 0) {  // chromosome change: back to [1,W], clamped (:169-175)
+            ws = 1;
+            we = ws + (W - 1);
+            if (len && we > len) we = len;
+        }
+        const uint64_t first = i, run_end = i + run_len[r];
+        uint64_t lo = i;
+        for (; i < run_end; ++i) {
+            const uint32_t p = pos[i];
+            if (len && p > len) return fail(PGT_EDOMAIN, "position beyond the chromosome length given with -chrlen");
+            // the site that triggers a chromosome change takes the `if` branch of :160 and is never tested
+            // against the window end; every other site (the very first of the file included) is (:176)
+            if ((r == 0 || i != first) && p >= we) {
+                emit(lo, i, (uint32_t)r, ws, we);
+                advance(len);
+                lo = i;
+                while (p > we) {  // empty windows in the gap (:184-189)
+                    emit(i, i, (uint32_t)r, ws, we);
+                    advance(len);
+                }
+            }
+        }
+        emit(lo, run_end, (uint32_t)r, ws, we);  // chromosome change (:161) or end of input (:212)
+        while (we < len) {                        // trailing windows up to the chromosome length (:162-167, :213-218)
+            advance(len);
+            emit(run_end, run_end, (uint32_t)r, ws, we);
+        }
+    }
+    *n_out = count;
+    if (out && count > cap) return fail(PGT_ECAP, "pgt_build_windows_extreme: output capacity too small");
+    return PGT_OK;
+}
+
 extern "C" int pgt_plan_shards(const pgt_win *win, uint64_t n_win, uint32_t n_ranks, pgt_shard *out) {
     if (!out || n_ranks == 0 || (n_win && !win)) return fail(PGT_EARG, "pgt_plan_shards: bad argument");
     uint64_t total = 0, max_len = 0;

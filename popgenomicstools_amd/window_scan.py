@@ -20,8 +20,9 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_STAT_DXY,
-                   PGT_STAT_FST, PGT_STAT_HET, SHARD_DTYPE, WIN_DTYPE, PgtError, check)
+from ._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, EXT_ROW_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_EXT_IHS,
+                   PGT_EXT_XP_MAX, PGT_EXT_XP_MIN, PGT_STAT_DXY, PGT_STAT_EXT, PGT_STAT_FST, PGT_STAT_HET,
+                   SHARD_DTYPE, WIN_DTYPE, PgtError, check)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -60,6 +61,24 @@ def build_windows_bp(pos, run_len, chr_len, W: int, S: int) -> np.ndarray:
     out = np.zeros(n_out.value, dtype=WIN_DTYPE)
     check(lib.pgt_build_windows_bp(p.ctypes.data, rl.ctypes.data, cl.ctypes.data, rl.size, W, S,
                                    out.ctypes.data, out.size, C.byref(n_out)))
+    return out
+
+
+def build_windows_extreme(pos, run_len, chr_len, W: int) -> np.ndarray:
+    """ihsWindow / xpehhWindow window table (ihsWindow.cpp:147-218); chr_len[r] = 0 or None where the
+    chromosome length is not given."""
+    lib = _lib.load()
+    p = np.ascontiguousarray(pos, dtype=np.uint32)
+    rl = np.ascontiguousarray(run_len, dtype=np.uint64)
+    cl = None if chr_len is None else np.ascontiguousarray(chr_len, dtype=np.uint32)
+    if int(rl.sum()) != p.size or (cl is not None and cl.size != rl.size):
+        raise PgtError(_lib.PGT_EARG, "build_windows_extreme: run_len / chr_len / pos sizes disagree")
+    n_out = C.c_size_t(0)
+    clp = cl.ctypes.data if cl is not None else None
+    check(lib.pgt_build_windows_extreme(p.ctypes.data, rl.ctypes.data, clp, rl.size, W, None, 0, C.byref(n_out)))
+    out = np.zeros(n_out.value, dtype=WIN_DTYPE)
+    check(lib.pgt_build_windows_extreme(p.ctypes.data, rl.ctypes.data, clp, rl.size, W, out.ctypes.data, out.size,
+                                        C.byref(n_out)))
     return out
 
 
@@ -126,6 +145,17 @@ class Context:
         out = np.zeros(win.size, dtype=HET_ROW_DTYPE)
         self._check(self._lib.pgt_het_reduce(self._ctx, pos.ctypes.data, g.ctypes.data, pos.size,
                                              win.ctypes.data, win.size, out.ctypes.data))
+        return out
+
+    def extreme_reduce(self, pos, score, mode, cutoff, win) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        score = np.ascontiguousarray(score, dtype=np.float64)
+        win = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+        if pos.size != score.size:
+            raise PgtError(_lib.PGT_EARG, "extreme_reduce: column lengths differ")
+        out = np.zeros(win.size, dtype=EXT_ROW_DTYPE)
+        self._check(self._lib.pgt_extreme_reduce(self._ctx, pos.ctypes.data, score.ctypes.data, pos.size, int(mode),
+                                                 float(cutoff), win.ctypes.data, win.size, out.ctypes.data))
         return out
 
     def dxy_reduce(self, pos, p1, p2, n1, n2, minind, win):
@@ -367,3 +397,32 @@ def dxy_window(chr_ids, pos, p1, p2, n1, n2, W: int = 0, S: int = 0, minind: int
         keep = rows["neff"] > 0
         win, rows = win[keep], rows[keep]
     return WindowResult(win, rows, tot)
+
+
+def ihs_window(chr_ids, pos, score, W: int = 100000, cutoff: float = 2.0, chr_len=None,
+               ctx: Context | None = None) -> WindowResult:
+    """ihsWindow.cpp:123-221 over columns (defaults of ihsWindow.cpp:225-226): rows are
+    (start, end, nsites, nbig, position, value); proportion = nbig / nsites."""
+    if cutoff < 0:
+        raise PgtError(_lib.PGT_EARG, "|iHS| cutoff must be >= zero")  # ihsWindow.cpp:60-63
+    win = build_windows_extreme(pos, run_lengths(chr_ids), chr_len, W)
+    ctx, own = _own_ctx(ctx)
+    try:
+        return WindowResult(win, ctx.extreme_reduce(pos, score, PGT_EXT_IHS, cutoff, win))
+    finally:
+        if own:
+            ctx.close()
+
+
+def xpehh_window(chr_ids, pos, score, cutoff: float, W: int = 100000, chr_len=None,
+                 ctx: Context | None = None) -> WindowResult:
+    """xpehhWindow.cpp:126-232 over columns: a negative cutoff looks for the minimum and counts
+    scores below it, otherwise the maximum / above (xpehhWindow.cpp:210-216)."""
+    win = build_windows_extreme(pos, run_lengths(chr_ids), chr_len, W)
+    mode = PGT_EXT_XP_MIN if cutoff < 0 else PGT_EXT_XP_MAX
+    ctx, own = _own_ctx(ctx)
+    try:
+        return WindowResult(win, ctx.extreme_reduce(pos, score, mode, cutoff, win))
+    finally:
+        if own:
+            ctx.close()

@@ -203,3 +203,40 @@ def test_cli_step_one_regime(hosts, tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     assert oracle.het_text(str(h), W, 1, str(o)) == 0
     assert r.stdout == o.read_text()  # integer counts: byte-identical
+
+
+def test_extreme_cli_arguments(hosts_ext, tmp_path):
+    """ihsWindow.cpp:37-79 / xpehhWindow.cpp:42-84: usage exits 1, bad arguments exit 255."""
+    f = tmp_path / "x.norm"
+    f.write_text("chr1_5\t5\t0.3\t1\t2\t0.5\t1.5\t0\n")
+    r = run([hosts_ext["ihsWindow"]])
+    assert r.returncode == 1 and "Must supply iHS input file" in r.stderr and "-cutoff FLOAT" in r.stdout
+    r = run([hosts_ext["xpehhWindow"], str(f)])
+    assert r.returncode == 1 and "Must supply XP-EHH file and cutoff value" in r.stderr
+    assert run([hosts_ext["ihsWindow"], str(tmp_path / "none.norm")]).returncode == 255
+    assert run([hosts_ext["ihsWindow"], str(f), "-winsize", "0"]).returncode == 255
+    assert run([hosts_ext["ihsWindow"], str(f), "-cutoff", "-1"]).returncode == 255
+    r = run([hosts_ext["xpehhWindow"], str(f), "2", "-nope", "1"])
+    assert r.returncode == 255 and "Unknown argument -nope" in r.stderr
+
+
+@pytest.fixture(scope="module")
+def hosts_ext(hosts):
+    return {t: os.path.join(BIN, t) for t in ("ihsWindow", "xpehhWindow")}
+
+
+@pytest.mark.gpu
+def test_extreme_cli_against_reference_goldens(hosts_ext, tmp_path):
+    cases = helpers.load_golden("ref_extreme.json")["cases"]
+    for i, c in enumerate(cases):
+        if i % 2:
+            continue
+        paths = {}
+        for name, text in c["files"].items():
+            p = tmp_path / name
+            p.write_text(text)
+            paths[name] = str(p)
+        argv = [hosts_ext[c["tool"]]] + [paths[a[1:]] if a.startswith("@") else a for a in c["args"]]
+        r = run(argv)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == c["stdout"], c["args"]  # selections and integer ratios: byte-identical

@@ -525,3 +525,78 @@ def test_device_entry_points_are_graph_capturable(pgt, ctx):
     torch.cuda.synchronize()
     again = rows_from_device(out, FST_ROW_DTYPE)
     assert np.array_equal(again["asum"], 2.0 * eager["asum"]) and np.array_equal(again["bsum"], 4.0 * eager["bsum"])
+
+
+# ---------------------------------------------------------------------------------------------
+# ihsWindow / xpehhWindow
+# ---------------------------------------------------------------------------------------------
+def _check_extreme(pgt, ctx, oracle, chr_ids, pos, score, W, mode, cutoff, chr_len):
+    ref = oracle.extreme_scan(chr_ids, pos, score, W, mode, cutoff, chr_len)
+    if mode == 0:
+        res = pgt.ihs_window(chr_ids, pos, score, W, cutoff, chr_len, ctx=ctx)
+    else:
+        res = pgt.xpehh_window(chr_ids, pos, score, cutoff, W, chr_len, ctx=ctx)
+    r = res.rows
+    assert r.size == ref.size
+    for f in ("start", "end", "nsites", "nbig", "position"):
+        assert np.array_equal(r[f], ref[f]), f
+    assert np.array_equal(r["value"], ref["value"])  # a selection, not arithmetic: bit-exact
+    assert np.array_equal(res.win["label_run"], ref["label"])
+    return r
+
+
+@pytest.mark.parametrize("n,W", [(1, 10), (127, 50), (129, 1), (8193, 500), (300_000, 100_000), (1_000_000, 2_000_000), (700_001, 777)])
+def test_extreme_vs_oracle(pgt, ctx, oracle, n, W):
+    rng = np.random.default_rng(n + W)
+    chr_ids, pos = synth.chromosomes(rng, n, min(n, 4), equal=False)
+    score = np.round(rng.normal(0, 1.5, n), 6)
+    score[rng.integers(0, n, size=max(1, n // 20))] = rng.choice([2.0, -2.0, 0.0, 3.25, -3.25])  # ties, cutoff-equal values
+    runs = pgt.run_lengths(chr_ids)
+    ends = np.cumsum(runs).astype(np.int64) - 1
+    chr_len = (pos[ends].astype(np.int64) + rng.integers(0, 3 * W, size=runs.size)).astype(np.uint32)
+    for mode, cutoff in ((0, 2.0), (1, 2.0), (2, -2.0), (1, 0.0)):
+        for cl in (chr_len, None):
+            _check_extreme(pgt, ctx, oracle, chr_ids, pos, score, W, mode, cutoff, cl)
+
+
+def _parse_norm(text, tool):
+    lines = text.splitlines()
+    if tool == "xpehhWindow":
+        lines = lines[1:]
+    names, chr_ids, pos, score = [], [], [], []
+    for ln in lines:
+        t = ln.split()
+        c = t[0].split("_")[0]
+        if not names or names[-1] != c:
+            names.append(c)
+        chr_ids.append(len(names) - 1)
+        pos.append(int(t[1]))
+        score.append(float(t[2 + (4 if tool == "ihsWindow" else 6)]))
+    return names, np.array(chr_ids, np.uint32), np.array(pos, np.uint32), np.array(score)
+
+
+def test_extreme_golden_fixtures(pgt, ctx):
+    """Rows against the TSV printed by the unmodified ihsWindow / xpehhWindow binaries."""
+    n = 0
+    for c in helpers.load_golden("ref_extreme.json")["cases"]:
+        names, chr_ids, pos, score = _parse_norm(c["files"]["in.norm"], c["tool"])
+        a = c["args"]
+        W = int(a[a.index("-winsize") + 1])
+        chr_len = None
+        if "-chrlen" in a:
+            lens = dict(ln.split() for ln in c["files"]["len.txt"].splitlines())
+            chr_len = np.array([int(lens.get(nm, 0)) for nm in names], dtype=np.uint32)
+        if c["tool"] == "ihsWindow":
+            res = pgt.ihs_window(chr_ids, pos, score, W, float(a[a.index("-cutoff") + 1]), chr_len, ctx=ctx)
+        else:
+            res = pgt.xpehh_window(chr_ids, pos, score, float(a[1]), W, chr_len, ctx=ctx)
+        out = []
+        for w, r in zip(res.win, res.rows):
+            head = f"{names[int(w['label_run'])]}\t{int(r['start'])}\t{int(r['end'])}\t"
+            if r["nsites"]:
+                out.append(head + f"{helpers.fmt_g(r['value'])}\t{int(r['position'])}\t{helpers.fmt_g(int(r['nbig']) / int(r['nsites']))}\t{int(r['nsites'])}")
+            else:
+                out.append(head + "NA\tNA\tNA\t0")
+        assert "\n".join(out) + "\n" == c["stdout"], a
+        n += 1
+    assert n >= 100

@@ -117,3 +117,43 @@ def test_golden_window_counts(pgt):
         for w, t in zip(win, tsv):
             assert names[int(w["label_run"])] == t[0]
             assert str(int(pos[int(w["lo"])])) == t[1] and str(int(pos[int(w["hi"]) - 1])) == t[2]
+
+
+def test_extreme_windows_match_tool_loop(oracle, pgt):
+    """pgt_build_windows_extreme against the oracle's run of the ihsWindow/xpehhWindow loop."""
+    rng = np.random.default_rng(3)
+    n_windows = 0
+    for trial in range(1500):
+        W = int(rng.choice([1, 2, 5, 10, 37, 100]))
+        n_runs = int(rng.integers(1, 5))
+        pos_l, chr_l, len_l = [], [], []
+        for r in range(n_runs):
+            k = int(rng.integers(1, 30))
+            p = np.cumsum(rng.integers(0 if rng.random() < 0.2 else 1, max(2, W), size=k)) + 1  # duplicates allowed
+            pos_l.append(p)
+            chr_l.append(np.full(k, r))
+            len_l.append(0 if rng.random() < 0.4 else int(p[-1]) + int(rng.integers(0, 3 * W)))
+        pos = np.concatenate(pos_l).astype(np.uint32)
+        chr_ids = np.concatenate(chr_l).astype(np.uint32)
+        chr_len = np.array(len_l, dtype=np.uint32)
+        use_len = chr_len if rng.random() < 0.8 else None
+        rows = oracle.extreme_scan(chr_ids, pos, np.zeros(pos.size), W, 0, 2.0, use_len)
+        win = pgt.build_windows_extreme(pos, pgt.run_lengths(chr_ids), use_len, W)
+        assert win.size == rows.size, (W, pos_l, len_l)
+        assert np.array_equal(win["start"], rows["start"]) and np.array_equal(win["end"], rows["end"])
+        assert np.array_equal(win["label_run"], rows["label"])
+        assert np.array_equal(win["hi"] - win["lo"], rows["nsites"])
+        ne = rows["nsites"] > 0
+        assert np.array_equal(win["lo"][ne], rows["lo"][ne]) and np.array_equal(win["hi"][ne], rows["hi"][ne])
+        n_windows += win.size
+    assert n_windows > 10000
+
+
+def test_extreme_builder_domain(pgt):
+    with pytest.raises(_lib.PgtError):  # position beyond a given chromosome length: the reference never terminates
+        pgt.build_windows_extreme(np.array([5, 30], dtype=np.uint32), np.array([2], dtype=np.uint64),
+                                  np.array([20], dtype=np.uint32), 10)
+    with pytest.raises(_lib.PgtError):
+        pgt.build_windows_extreme(np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint64), None, 10)
+    with pytest.raises(_lib.PgtError):
+        pgt.build_windows_extreme(np.array([5], dtype=np.uint32), np.array([1], dtype=np.uint64), None, 0)
