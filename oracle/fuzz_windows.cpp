@@ -72,6 +72,25 @@ int main(int argc, char **argv) {
             if (bref[i].hi == bref[i].lo && bwin[i].lo != bwin[i].hi) return fail("bp empty", t);
         }
         windows += n_out;
+        // ---- ihsWindow / xpehhWindow windows (non-overlapping bp windows, history dependent)
+        {
+            const uint32_t We = (uint32_t)U(1, 60);
+            std::vector<uint32_t> elen(n_runs);
+            for (int r = 0; r < n_runs; ++r) elen[r] = rng() % 3 == 0 ? 0u : std::max(chr_len[r], 121u) + (uint32_t)U(0, 100);
+            // elen >= every position of the run (positions are <= 120), or 0 = unknown
+            if (pgt_build_windows_extreme(pos.data(), run_len.data(), elen.data(), run_len.size(), We, nullptr, 0, &n_out) != PGT_OK) return fail("ext count", t);
+            std::vector<pgt_win> ewin(n_out + 1);
+            if (pgt_build_windows_extreme(pos.data(), run_len.data(), elen.data(), run_len.size(), We, ewin.data(), ewin.size(), &n_out) != PGT_OK) return fail("ext fill", t);
+            std::vector<orc_ext_row> eref(n_out + 8);
+            if (orc_extreme_scan(chr.data(), pos.data(), ones.data(), n, We, ORC_EXT_IHS, 2.0, elen.data(), elen.size(), eref.data(), eref.size(), &n_ref) != ORC_OK) return fail("oracle ext", t);
+            if (n_ref != n_out) return fail("ext window count", t);
+            for (size_t i = 0; i < n_out; ++i) {
+                if (ewin[i].start != eref[i].start || ewin[i].end != eref[i].end || ewin[i].label_run != eref[i].label) return fail("ext coords", t);
+                if (ewin[i].hi - ewin[i].lo != eref[i].nsites) return fail("ext nsites", t);
+                if (eref[i].nsites && (ewin[i].lo != eref[i].lo || ewin[i].hi != eref[i].hi)) return fail("ext sites", t);
+            }
+            windows += n_out;
+        }
     }
     std::printf("fuzz_windows: %d trials, %zu windows, all equal\n", trials, windows);
     return 0;

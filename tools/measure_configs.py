@@ -67,6 +67,20 @@ def main():
     row(f"3b: hetWindow alone {n:.0e}", 1, timed(ctx, lambda: ctx.het_reduce_dev(pos, g1, win, out=out, tree=tree)))
     row(f"3: dxy + het x2 fused {n:.0e}", 26, timed(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)))
     del p1, p2, n1, n2, g1, g2
+    # ihsWindow-style extreme-score scan: one f64 score column, 100 kb non-overlapping windows
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_STAT_EXT
+    hpos = pos.cpu().numpy().view(np.uint32)
+    ewin_h = pgt.build_windows_extreme(hpos, run_len, None, 100_000)
+    ewin = windows_to_device(ewin_h, dev)
+    eout = torch.empty(ewin_h.size * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    lib = pgt._lib.load()
+    import ctypes as C
+    def ext_call():
+        ctx._check(lib.pgt_extreme_reduce_dev(ctx._ctx, pos.data_ptr(), a.data_ptr(), n, 0, 2.0, ewin.data_ptr(), ewin_h.size,
+                                              eout.data_ptr(), tree.data_ptr(), tree.numel(), ctx._stream(None)))
+    ctx.set_max_window(int((ewin_h["hi"] - ewin_h["lo"]).max()))
+    row(f"ihsWindow-style extreme scan {n:.0e} ({ewin_h.size} windows)", 8, timed(ctx, ext_call))
+    ctx.set_max_window(W)
     if big:
         print(f"\n({n:.0e} sites: 28-pair and host-buffer legs skipped)")
         ctx.close()
