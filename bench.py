@@ -190,11 +190,15 @@ def main():
         for _ in range(3):
             ctx.fst_reduce_dev(pos[:n8], a[:n8], b[:n8], win8, out=out8, tree=tree)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
+        # per-step time from events on the launch stream (= torch's current stream); median of 50,
+        # so that a one-off stall inside the loop does not pass for a per-step cost
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for e0, e1 in ev:
+            e0.record()
             ctx.fst_reduce_dev(pos[:n8], a[:n8], b[:n8], win8, out=out8, tree=tree)
+            e1.record()
         torch.cuda.synchronize()
-        d8 = (time.perf_counter() - t1) / 50
+        d8 = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e-3
         ctx.set_profiling(True)
         b8 = []
         for _ in range(10):
