@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--chroms", type=int, default=40, help="chromosomes per GPU")
     ap.add_argument("--winsize", type=int, default=50_000)
     ap.add_argument("--stepsize", type=int, default=10_000)
-    ap.add_argument("--cpu-sites", type=float, default=1e7, help="sample size of the CPU baseline leg")
+    ap.add_argument("--cpu-sites", type=float, default=5e7,
+                    help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra", action="store_true",
                     help="also time the 10^8-site configuration (BASELINE configs[1]) on the same buffers; off by "

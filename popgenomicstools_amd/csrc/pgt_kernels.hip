@@ -48,6 +48,11 @@ template <> __device__ __forceinline__ NodeExt node_identity<NodeExt>() {
 }
 
 __device__ __forceinline__ void node_add(NodeFst &a, const NodeFst &b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void node_add(NodeHet &a, const NodeHet &b) { a.nonmiss += b.nonmiss; a.nhet += b.nhet; }
+__device__ __forceinline__ void node_add(NodeDxy &a, const NodeDxy &b) { a.s += b.s; a.neff += b.neff; a.nskip += b.nskip; }
+__device__ __forceinline__ NodeFst node_wave_sum(NodeFst v) { return {wave_sum(v.x), wave_sum(v.y)}; }
+__device__ __forceinline__ NodeHet node_wave_sum(NodeHet v) { return {wave_sum(v.nonmiss), wave_sum(v.nhet)}; }
+__device__ __forceinline__ NodeDxy node_wave_sum(NodeDxy v) { return {wave_sum(v.s), wave_sum(v.neff), wave_sum(v.nskip)}; }
 __device__ __forceinline__ void node_add(NodeExt &a, const NodeExt &b) {
     a.count += b.count;
     if (b.key > a.key || (b.key == a.key && b.idx < a.idx)) { a.key = b.key; a.idx = b.idx; }
@@ -62,11 +67,6 @@ __device__ __forceinline__ NodeExt node_wave_sum(NodeExt v) {
     o = {__shfl_xor(v.key, 32, kWave), (uint32_t)__shfl_xor((int)v.idx, 32, kWave), (uint32_t)__shfl_xor((int)v.count, 32, kWave)}; node_add(v, o);
     return v;
 }
-__device__ __forceinline__ void node_add(NodeHet &a, const NodeHet &b) { a.nonmiss += b.nonmiss; a.nhet += b.nhet; }
-__device__ __forceinline__ void node_add(NodeDxy &a, const NodeDxy &b) { a.s += b.s; a.neff += b.neff; a.nskip += b.nskip; }
-__device__ __forceinline__ NodeFst node_wave_sum(NodeFst v) { return {wave_sum(v.x), wave_sum(v.y)}; }
-__device__ __forceinline__ NodeHet node_wave_sum(NodeHet v) { return {wave_sum(v.nonmiss), wave_sum(v.nhet)}; }
-__device__ __forceinline__ NodeDxy node_wave_sum(NodeDxy v) { return {wave_sum(v.s), wave_sum(v.neff), wave_sum(v.nskip)}; }
 
 constexpr int kMaxPairs = 32;
 struct PairCols {
