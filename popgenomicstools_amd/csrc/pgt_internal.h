@@ -14,6 +14,7 @@ constexpr int kWave = 64;        // gfx950 wavefront
 constexpr int kRadix = 64;       // children per tree node above the leaf level = one lane each
 constexpr int kLeafF64 = 128;    // sites per level-1 node for f64 columns: one 16-B load per lane
 constexpr int kLeafI8 = 1024;    // sites per level-1 node for the int8 genotype column: 16 B per lane
+constexpr int kLeafExt = 256;    // sites per level-1 node for the single-column extreme-score scan: 2 x 16 B per lane
 constexpr int kMaxLevels = 8;
 
 // Node sizes in bytes (all levels of one tree use the same node type).
@@ -28,7 +29,7 @@ struct TreeLayout {
     size_t bytes = 0;
 };
 
-inline int leaf_sites(int stat) { return stat == PGT_STAT_HET ? kLeafI8 : kLeafF64; }
+inline int leaf_sites(int stat) { return stat == PGT_STAT_HET ? kLeafI8 : (stat == PGT_STAT_EXT ? kLeafExt : kLeafF64); }
 inline size_t node_bytes(int stat) { return stat == PGT_STAT_HET ? kNodeHet : 16; }
 
 // Level 1 and 2 come out of the streaming build kernel; higher levels are added while a level

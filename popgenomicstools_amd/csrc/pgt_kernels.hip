@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
 
 // ------------------------------------------------------------------------------------------
 // BUILD, extreme score (ihsWindow / xpehhWindow): level-1 {key max, first index, count beyond the
-// cutoff} per 128 sites, level-2 per 8192 sites.                                  8 B/site read.
+// cutoff} per 256 sites, level-2 per 16384 sites.                                 8 B/site read.
 // ------------------------------------------------------------------------------------------
 struct ExtBuildArgs { const double *s; int mode; double thr; };
 __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv);
@@ -453,7 +453,7 @@ struct DxyTraits {
 struct ExtTraits {
     using Node = NodeExt;
     using Row = pgt_ext_row;
-    static constexpr int kLeaf = kLeafF64;
+    static constexpr int kLeaf = kLeafExt;
     struct Args { const double *s; int mode; double thr; };
     using Cols = Args;
     static __device__ __forceinline__ Cols cols(const Args &g, int) { return g; }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     NodeExt *__restrict__ l1 = reinterpret_cast<NodeExt *>(tv.base + tv.off[0]);
     NodeExt *__restrict__ l2 = reinterpret_cast<NodeExt *>(tv.base + tv.off[1]);
-    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+    constexpr uint64_t kTile2 = (uint64_t)kLeafExt * kRadix;  // 16384 sites
     auto site = [&](double s, uint64_t i) {
         const double k = ExtTraits::key_of(s, g.mode);
         return NodeExt{k, (uint32_t)i, (uint32_t)(k > g.thr)};
@@ -501,26 +501,33 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t
         if (base + kTile2 <= n) {
             const double2 *__restrict__ ps = reinterpret_cast<const double2 *>(g.s + base);
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += 8) {
-                double2 v[8];
+            for (int j = 0; j < kRadix; j += 4) {
+                double2 v[4][2];  // leaf tile = 256 sites = two 1-KiB wave loads; 8 loads in flight per lane
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = load16<true>(ps + (j + u) * kWave + lane);
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint64_t i0 = base + (uint64_t)(j + u) * kLeafF64 + 2 * lane;
-                    NodeExt a = site(v[u].x, i0);
-                    node_add(a, site(v[u].y, i0 + 1));
+                    for (int h = 0; h < 2; ++h) v[u][h] = load16<true>(ps + ((j + u) * 2 + h) * kWave + lane);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t t0 = base + (uint64_t)(j + u) * kLeafExt;
+                    NodeExt a = node_identity<NodeExt>();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {  // 4 sites per lane, combined before any cross-lane step
+                        const uint64_t i0 = t0 + (uint64_t)h * 2 * kWave + 2 * lane;
+                        node_add(a, site(v[u][h].x, i0));
+                        node_add(a, site(v[u][h].y, i0 + 1));
+                    }
                     a = node_wave_sum(a);
                     if (lane == j + u) keep = a;
                 }
             }
         } else {  // last, partial level-2 tile
             for (int j = 0; j < kRadix; ++j) {
-                const uint64_t tile0 = base + (uint64_t)j * kLeafF64;
+                const uint64_t tile0 = base + (uint64_t)j * kLeafExt;
                 if (tile0 >= n) break;  // wave-uniform
                 NodeExt a = node_identity<NodeExt>();
-                for (int q = 0; q < 2; ++q) {
-                    const uint64_t i = tile0 + 2 * lane + q;
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t i = tile0 + (uint64_t)(q >> 1) * 2 * kWave + 2 * lane + (q & 1);
                     if (i < n) node_add(a, site(g.s[i], i));
                 }
                 a = node_wave_sum(a);
@@ -558,15 +565,20 @@ __device__ __forceinline__ void ragged_pair(typename Tr::Node &acc, const typena
     if (l0 >= l1 && r0 >= r1) return;  // wave-uniform
     const Node none = node_identity<Node>();
     if (level == 0) {
-        if constexpr (Tr::kLeaf <= 2 * kWave) {
+        if constexpr (Tr::kLeaf <= 4 * kWave) {
+            constexpr int kSlots = Tr::kLeaf / kWave;  // per side: 2 for 128-site leaves, 4 for 256
             const uint64_t last = n_sites - 1;  // some valid site: a non-empty range implies n_sites > 0
-            const uint64_t idx[4] = {l0 + lane, l0 + lane + kWave, r0 + lane, r0 + lane + kWave};
-            const uint64_t end[4] = {l1, l1, r1, r1};
-            Node v[4];
+            Node v[2 * kSlots];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = Tr::leaf(c, idx[u] < end[u] ? idx[u] : last);
+            for (int u = 0; u < 2 * kSlots; ++u) {
+                const uint64_t i = (u < kSlots ? l0 : r0) + lane + (uint64_t)(u % kSlots) * kWave;
+                v[u] = Tr::leaf(c, i < (u < kSlots ? l1 : r1) ? i : last);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) node_add(acc, idx[u] < end[u] ? v[u] : none);
+            for (int u = 0; u < 2 * kSlots; ++u) {
+                const uint64_t i = (u < kSlots ? l0 : r0) + lane + (uint64_t)(u % kSlots) * kWave;
+                node_add(acc, i < (u < kSlots ? l1 : r1) ? v[u] : none);
+            }
         } else {  // int8 genotypes: up to 1023 sites per side, 16 per lane and load (own vector path)
             Tr::sum_sites(acc, c, l0, l1, lane, n_sites);
             Tr::sum_sites(acc, c, r0, r1, lane, n_sites);
