@@ -67,3 +67,26 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "liboracle" not in text and "window_oracle" not in text and "oracle_bind" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pgtwin.h must compile as C99 (no C++-isms): it is what a C / cgo / FFI binding includes.
+    A small C program that links the library also proves the symbols have C linkage."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "pgtwin.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    src = tmp_path / "t.c"
+    src.write_text('#include "pgtwin.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  uint64_t runs[2] = {7, 5}; size_t n = 0;\n'
+                   '  if (pgt_abi_version() != PGT_ABI_VERSION) return 2;\n'
+                   '  if (pgt_build_windows_sites(runs, 2, 5, 2, NULL, 0, &n) != PGT_OK) return 3;\n'
+                   '  if (pgt_build_windows_sites(runs, 2, 2, 5, NULL, 0, &n) != PGT_EARG) return 4;\n'
+                   '  printf("%zu %s\\n", n, pgt_last_error(NULL));\n  return 0;\n}\n')
+    exe = tmp_path / "t"
+    pkg = os.path.join(ROOT, "popgenomicstools_amd")
+    subprocess.run(["gcc", "-std=c99", str(src), "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-lpgtwin",
+                    "-Wl,-rpath," + pkg, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1 <= step <= window" in r.stdout
