@@ -122,6 +122,9 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 }
 
 // ---- BUILD: one wave per level-2 tile (64 leaf tiles of 128 sites) ------------------------------
+// (Tried: 256-site leaf tiles so that the reduce-scatter runs half as often: no gain at 8
+// populations, 53.6 % vs 56.7 % of HBM peak.  The kernel is bound by the 2 x (NP*3 + pairs*2) f64
+// operations per lane and tile and by occupancy — 188 VGPRs, 2 waves per SIMD — not by the exchanges.)
 template <int NP>
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;

@@ -34,10 +34,8 @@ inline size_t node_bytes(int stat) { return stat == PGT_STAT_HET ? kNodeHet : 16
 
 // Level 1 and 2 come out of the streaming build kernel; higher levels are added while a level
 // still has more than 64 nodes (so the top level is always reducible by one wave-wide load).
-inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
+inline TreeLayout tree_layout_for(uint64_t leaf, size_t nb, uint64_t n_sites) {
     TreeLayout t;
-    const uint64_t leaf = (uint64_t)leaf_sites(stat);
-    const size_t nb = node_bytes(stat);
     uint64_t n_l2 = (n_sites + leaf * kRadix - 1) / (leaf * kRadix);
     if (n_l2 == 0) n_l2 = 1;
     uint64_t c = n_l2 * kRadix;
@@ -60,19 +58,25 @@ inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
     t.bytes = off;
     return t;
 }
+inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
+    return tree_layout_for((uint64_t)leaf_sites(stat), node_bytes(stat), n_sites);
+}
 
 // Levels worth building when no window is longer than max_window sites (0 = unknown: all).
 // Level k (k >= 3) has nodes of leaf*64^(k-1) sites; a window can only contain such a node if it
 // is at least that long.  Levels 1 and 2 always exist (the build kernels write them).
-inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
+inline int useful_levels_for(const TreeLayout &t, uint64_t leaf, uint64_t max_window) {
     if (max_window == 0) return t.n_levels;
     int k = 2;
-    uint64_t node = (uint64_t)leaf_sites(stat) * kRadix * kRadix;  // level-3 node
+    uint64_t node = leaf * kRadix * kRadix;  // level-3 node
     while (k < t.n_levels && node <= max_window) {
         ++k;
         node *= kRadix;
     }
     return k;
+}
+inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
+    return useful_levels_for(t, (uint64_t)leaf_sites(stat), max_window);
 }
 
 // ---- allele-frequency front end (pgt_af_kernels.hip): V scalar trees, structure-of-arrays -----
