@@ -600,3 +600,63 @@ def test_extreme_golden_fixtures(pgt, ctx):
         assert "\n".join(out) + "\n" == c["stdout"], a
         n += 1
     assert n >= 100
+
+
+def test_device_api_argument_checks(pgt, ctx):
+    """Misaligned columns, undersized workspace and per-call site limits are refused before any launch."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 10_000
+    a = torch.rand(n + 1, dtype=torch.float64, device=dev)
+    pos = torch.arange(n, dtype=torch.int32, device=dev)
+    win = windows_to_device(pgt.build_windows_sites(np.array([n], dtype=np.uint64), 1000, 500), dev)
+    with pytest.raises(_lib.PgtError):  # 8-byte (not 16-byte) aligned column
+        ctx.fst_reduce_dev(pos, a[1:], a[:n], win)
+    small = torch.empty(256, dtype=torch.uint8, device=dev)
+    with pytest.raises(_lib.PgtError):  # workspace too small
+        ctx.fst_reduce_dev(pos, a[:n], a[:n], win, tree=small)
+    lib = _lib.load()
+    g = torch.zeros(1024, dtype=torch.int8, device=dev)
+    tree = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    out = torch.empty(win.numel() // 32 * 32, dtype=torch.uint8, device=dev)
+    rc = lib.pgt_het_reduce_dev(ctx._ctx, pos.data_ptr(), g.data_ptr(), 1 << 32, win.data_ptr(), 1, out.data_ptr(),
+                                tree.data_ptr(), tree.numel(), None)
+    assert rc == _lib.PGT_EARG and b"2^32" in lib.pgt_last_error(ctx._ctx)  # refused before touching memory
+    rc = lib.pgt_extreme_reduce_dev(ctx._ctx, pos.data_ptr(), a.data_ptr(), n, 7, 2.0, win.data_ptr(), 1, out.data_ptr(),
+                                    tree.data_ptr(), tree.numel(), None)
+    assert rc == _lib.PGT_EARG  # unknown mode
+
+
+def test_fst_beyond_2_32_sites(pgt, ctx):
+    """Maximum sizes: 4.4e9 sites (88 GB of columns) — site indices above 2^32 in the table, the tree
+    and the kernels' address arithmetic.  Windows at the far end against float64 sums by torch."""
+    import torch
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info()
+    n = 4_400_000_000
+    if free < 110e9:
+        pytest.skip("needs ~110 GB of free HBM")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    a = torch.empty(n, dtype=torch.float64, device=dev)
+    b = torch.empty(n, dtype=torch.float64, device=dev)
+    step = 400_000_000
+    for o in range(0, n, step):
+        m = min(step, n - o)
+        b[o:o + m] = torch.rand(m, generator=gen, device=dev, dtype=torch.float64)
+        a[o:o + m] = b[o:o + m] * 0.25
+    pos = torch.ones(n, dtype=torch.int32, device=dev)  # coordinates are not the point here
+    W, S = 50_000, 10_000
+    win = pgt.build_windows_sites(np.array([n], dtype=np.uint64), W, S)
+    assert win["hi"].max() == n and (win["lo"] > 2**32).sum() > 1000
+    tail = win[-2000:]  # windows whose site range lies entirely above 2^32
+    out, _ = ctx.fst_reduce_dev(pos, a, b, windows_to_device(tail, dev))
+    torch.cuda.synchronize()
+    rows = rows_from_device(out, FST_ROW_DTYPE)
+    assert np.array_equal(rows["n"], (tail["hi"] - tail["lo"]).astype(np.uint32))
+    for i in (0, 1, 777, 1998, 1999):
+        lo, hi = int(tail["lo"][i]), int(tail["hi"][i])
+        assert_close([rows["bsum"][i]], [float(b[lo:hi].sum())], "bsum above 2^32")
+        assert_close([rows["asum"][i]], [float(a[lo:hi].sum())], "asum above 2^32")
+    assert_close(rows["fst"], np.full(rows.size, 0.25), "fst above 2^32")
+    del a, b, pos
+    torch.cuda.empty_cache()
