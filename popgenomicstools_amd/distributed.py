@@ -78,3 +78,33 @@ def gather_rows(local_rows, counts, row_bytes: int, dst: int = 0, group=None):
     if rank != dst:
         return None
     return torch.cat([recv[r][: int(counts[r]) * row_bytes] for r in range(world)])
+
+
+def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows, device, dst: int = 0, group=None):
+    """The whole multi-GPU path for one input, to be called by every rank of the process group.
+
+      win           the full window table (identical on every rank; built on the host in O(#windows))
+      load_columns  callable(site_lo, site_hi) -> whatever reduce_rows needs for sites [site_lo, site_hi):
+                    a rank only ever touches its own shard (plus a halo of at most one window)
+      reduce_rows   callable(columns, local_win) -> packed uint8 torch tensor of len(local_win) rows on
+                    `device` (e.g. lambda c, w: ctx.fst_reduce_dev(*c, windows_to_device(w, dev))[0])
+    Returns on `dst` the assembled rows as a numpy structured array in window order, None elsewhere.
+    One collective: the gather of the fixed-size rows (RCCL when the backend is nccl).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    shard, local_win, shards = shard_windows(win, rank, world)
+    columns = load_columns(int(shard["site_lo"]), int(shard["site_hi"]))
+    rows = reduce_rows(columns, local_win)
+    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64)
+    if world == 1:
+        packed = rows
+    else:
+        parts = RowGatherer(counts, row_dtype.itemsize, device, dst=dst, group=group)(rows)
+        packed = torch.cat(parts) if rank == dst else None
+    if rank != dst:
+        return None
+    return np.frombuffer(packed.cpu().numpy().tobytes(), dtype=row_dtype)

@@ -16,7 +16,7 @@ import oracle_bind  # noqa: E402
 import synth  # noqa: E402
 from popgenomicstools_amd import build_windows_sites, run_lengths  # noqa: E402
 from popgenomicstools_amd._lib import FST_ROW_DTYPE  # noqa: E402
-from popgenomicstools_amd.distributed import RowGatherer, gather_rows, shard_windows  # noqa: E402
+from popgenomicstools_amd.distributed import RowGatherer, gather_rows, shard_windows, sharded_scan  # noqa: E402
 
 
 def cpu_reduce(pos, a, b, win):
@@ -57,6 +57,12 @@ def main():
         assert np.array_equal(got["fst"], ref["value"])  # same sequential order -> same bits
         assert counts.min() > 0
         print("GLOO_OK", win.size, counts.tolist())
+    # the one-call form of the same path
+    got2 = sharded_scan(win, FST_ROW_DTYPE, lambda lo_, hi_: (pos[lo_:hi_], a[lo_:hi_], b[lo_:hi_]),
+                        lambda c, w: torch.from_numpy(cpu_reduce(*c, w).view(np.uint8).copy()), torch.device("cpu"))
+    if rank == 0:
+        assert got2.tobytes() == got.tobytes()
+        print("GLOO_OK sharded_scan")
     dist.barrier()
     dist.destroy_process_group()
 

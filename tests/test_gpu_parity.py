@@ -660,3 +660,26 @@ def test_fst_beyond_2_32_sites(pgt, ctx):
     assert_close(rows["fst"], np.full(rows.size, 0.25), "fst above 2^32")
     del a, b, pos
     torch.cuda.empty_cache()
+
+
+def test_sharded_scan_single_rank_rccl(pgt, ctx):
+    """distributed.sharded_scan on the RCCL backend with the one rank a 1-GPU box offers: shard plan,
+    shard-local columns on the device, reduce through the C-ABI, assembly — equal to the plain call."""
+    import torch
+    import torch.distributed as dist
+    from popgenomicstools_amd.distributed import sharded_scan
+    rng = np.random.default_rng(61)
+    n = 400_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29534", world_size=1, rank=0, device_id=dev)
+    try:
+        def load(lo, hi):
+            return (torch.from_numpy(pos[lo:hi].view(np.int32)).to(dev), torch.from_numpy(a[lo:hi]).to(dev),
+                    torch.from_numpy(b[lo:hi]).to(dev))
+        rows = sharded_scan(win, FST_ROW_DTYPE, load, lambda c, w: ctx.fst_reduce_dev(*c, windows_to_device(w, dev))[0], dev)
+    finally:
+        dist.destroy_process_group()
+    assert rows.tobytes() == ctx.fst_reduce(pos, a, b, win).tobytes()
