@@ -127,3 +127,85 @@ def test_extreme_tools_byte_identical(oracle, tmp_path):
             rc = oracle.xpehh_text(src, cutoff, W, chrlen, str(out))
         assert rc == 0 and c["rc"] == 0
         assert out.read_text() == c["stdout"], c["args"]
+
+
+def test_dxy_fixedsite_windows_equal_the_pinned_fst_machine(oracle):
+    """dxyWindow -fixedsite 1 uses the same emission rules as fstWindow (dxyWindow.cpp:357-359,376-378,
+    424-426 vs fstWindow.cpp:132-138,150-152).  The fst restatement is pinned to the real binary, so
+    equality of the two oracles' window ranges pins the dxy restatement's fixed-site machine to it."""
+    rng = np.random.default_rng(17)
+    for _ in range(400):
+        n_runs = int(rng.integers(1, 6))
+        lens = rng.integers(1, 40, n_runs)
+        chr_ids = np.repeat(np.arange(n_runs, dtype=np.uint32), lens)
+        n = chr_ids.size
+        pos = np.arange(1, n + 1, dtype=np.uint32)
+        W = int(rng.integers(1, 14)); S = int(rng.integers(1, W + 1))
+        f = oracle.fst_scan(chr_ids, pos, np.ones(n), np.ones(n), W, S)
+        d, _ = oracle.dxy_scan(chr_ids, pos, np.full(n, 0.5), np.full(n, 0.5), np.full(n, 9, np.int32),
+                               np.full(n, 9, np.int32), W, S, 1, 1, 0)
+        assert d.size == f.size
+        for k in ("label", "start", "end", "lo", "hi"):
+            assert np.array_equal(d[k], f[k]), k
+        assert np.array_equal(d["n"], f["n"])  # every site is effective here
+
+
+def _slot_model(runs, W, S):
+    """Pure-Python model of dxyWindow's bp mode, written from SURVEY.md §4 ("the same machine run
+    over base-pair slots 1..chrlen, data site or placeholder, with the chromosome-change rule: emit only
+    if n > W-S; reset only if an emit happened and n < W").  runs = [(L, {pos: value})]."""
+    out, buf = [], []
+
+    def emit(label):
+        vals = [v for _, v in buf]
+        out.append((label, buf[0][0], buf[-1][0], sum(v for v in vals if v is not None and v >= 0),
+                    sum(1 for v in vals if v is not None and v >= 0), sum(1 for v in vals if v == -9)))
+
+    for r, (L, data) in enumerate(runs):
+        for slot in range(1, L + 1):
+            if len(buf) == W:
+                emit(r)
+                del buf[:S]
+            buf.append((slot, data.get(slot)))
+        last = r == len(runs) - 1
+        if not last and len(buf) > W - S:
+            full = len(buf) == W
+            emit(r)
+            if full:
+                del buf[:S]
+            else:
+                buf.clear()
+        if last and W - S < len(buf) <= W:
+            emit(r)
+    return out
+
+
+def test_dxy_bp_mode_equals_independent_slot_model(oracle):
+    rng = np.random.default_rng(23)
+    n_win = 0
+    for _ in range(500):
+        W = int(rng.integers(1, 15)); S = int(rng.integers(1, W + 1)); minind = 3
+        runs, chr_l, pos_l, p1_l, p2_l, n1_l, n2_l, len_l = [], [], [], [], [], [], [], []
+        for r in range(int(rng.integers(1, 5))):
+            L = int(rng.integers(1, 40))
+            k = int(rng.integers(1, min(L, 10) + 1))
+            pp = np.sort(rng.choice(np.arange(1, L + 1), size=k, replace=False))
+            f1, f2 = rng.uniform(0, 1, k).round(3), rng.uniform(0, 1, k).round(3)
+            m1, m2 = rng.integers(0, 7, k), rng.integers(0, 7, k)
+            data = {}
+            for q in range(k):
+                ok = m1[q] >= minind and m2[q] >= minind
+                data[int(pp[q])] = f1[q] * (1.0 - f2[q]) + f2[q] * (1.0 - f1[q]) if ok else -9
+            runs.append((L, data))
+            chr_l.append(np.full(k, r)); pos_l.append(pp); p1_l.append(f1); p2_l.append(f2); n1_l.append(m1); n2_l.append(m2)
+            len_l.append(L)
+        rows, tot = oracle.dxy_scan(np.concatenate(chr_l), np.concatenate(pos_l), np.concatenate(p1_l), np.concatenate(p2_l),
+                                    np.concatenate(n1_l).astype(np.int32), np.concatenate(n2_l).astype(np.int32), W, S,
+                                    minind, 0, 0, np.array(len_l, dtype=np.uint32))
+        model = _slot_model(runs, W, S)
+        assert len(model) == rows.size
+        for m, r in zip(model, rows):
+            assert (m[0], m[1], m[2], m[4], m[5]) == (r["label"], r["start"], r["end"], r["n"], r["nskip"])
+            assert abs(m[3] - r["value"]) <= 1e-12
+        n_win += rows.size
+    assert n_win > 3000
