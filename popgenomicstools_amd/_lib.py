@@ -103,10 +103,8 @@ def load() -> C.CDLL:
     lib.pgt_set_profiling.argtypes = [vp, i32]
     lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pgt_plan_shards.argtypes = [vp, u64, u32, vp]
-    for name in SYMBOLS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("pgt_abi_version",):
-            pass
+    for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
+        getattr(lib, name)
     _lib = lib
     return lib
 
