@@ -128,26 +128,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs for a one-GPU box (never set by the driver): PGT_BENCH_BACKEND=gloo moves the
+    # collectives to CPU staging, PGT_BENCH_SHARE_GPU=1 puts every rank on GPU 0.  The measured
+    # configuration is always the default: one GPU per rank, backend nccl (= RCCL over xGMI).
+    backend = os.environ.get("PGT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("PGT_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     n, W, S = int(args.sites), args.winsize, args.stepsize
     pos, a, b, run_len = synth_columns(n, args.chroms, 12345 + rank, dev)
     win = pgt.build_windows_sites(run_len, W, S)  # host, O(#windows)
     win_d = windows_to_device(win, dev)
-    ctx = pgt.Context(local_rank)
+    ctx = pgt.Context(dev_index)
     ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
     tree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
     out = torch.empty(win.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     counts = [win.size] * world  # every rank has the same geometry
-    gather = RowGatherer(counts, FST_ROW_DTYPE.itemsize, dev, dst=0) if world > 1 else None
+    gather = RowGatherer(counts, FST_ROW_DTYPE.itemsize, coll_dev, dst=0) if world > 1 else None
 
     def step():
         ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
         if gather is not None:
-            return gather(out)  # one RCCL gather of 40 B/window to rank 0
+            return gather(out if coll_dev is dev else out.cpu())  # one RCCL gather of 40 B/window to rank 0
         return out
 
     def fence():
@@ -165,7 +174,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -239,7 +248,8 @@ def main():
                                    f"window {W} sites / step {S} sites, {win.size} windows per GPU, columns resident in HBM"
                                    + (", rows gathered to rank 0 over RCCL" if world > 1 else ""),
                        "sites_per_gpu": n, "winsize": W, "stepsize": S, "windows_per_gpu": int(win.size),
-                       "parallelism": f"site-range shards x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
+                                      if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "fst_build_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "kernel_ms": build_avg, "query_kernel_ms": float(np.mean(query_ms)),
