@@ -142,6 +142,80 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// BUILD, fst, LDS-DMA form: the same tiles, sums and node layout as fst_build_kernel, but each 1-KiB
+// piece goes global -> LDS directly (global_load_lds_dwordx4 ... nt, no VGPR destination) into a
+// ring private to the wave, which then reads its own 16 bytes back (ds_read_b128).  A load-only
+// probe streams 6.7 TB/s this way against 6.4 TB/s through registers (profiles/r01/stream_probe.md).
+// No barrier: a wave only ever reads what it loaded itself; the DMA is ordered by vmcnt.
+// Ring = 2 buffers x 2 columns x GROUP pieces of 1 KiB per wave.
+// ------------------------------------------------------------------------------------------
+template <int GROUP>
+__global__ __launch_bounds__(256) void fst_build_lds_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
+    extern __shared__ __attribute__((aligned(16))) char lds_ring[];
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const double *__restrict__ a = cols.a[blockIdx.y];
+    const double *__restrict__ b = cols.b[blockIdx.y];
+    char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
+    NodeFst *__restrict__ l1 = reinterpret_cast<NodeFst *>(tree + tv.off[0]);
+    NodeFst *__restrict__ l2 = reinterpret_cast<NodeFst *>(tree + tv.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+    char *ring = lds_ring + (size_t)wib * (2 * 2 * GROUP * 1024);
+    using lds_ptr = __attribute__((address_space(3))) void *;
+
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        double keep_a = 0.0, keep_b = 0.0;
+        if (base + kTile2 <= n) {
+            const double2 *pa = reinterpret_cast<const double2 *>(a + base);
+            const double2 *pb = reinterpret_cast<const double2 *>(b + base);
+            auto issue = [&](int buf, int j) {
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) {
+                    __builtin_amdgcn_global_load_lds(pa + (j + u) * kWave + lane, (lds_ptr)(ring + ((buf * 2 + 0) * GROUP + u) * 1024), 16, 0, 2);
+                    __builtin_amdgcn_global_load_lds(pb + (j + u) * kWave + lane, (lds_ptr)(ring + ((buf * 2 + 1) * GROUP + u) * 1024), 16, 0, 2);
+                }
+            };
+            issue(0, 0);
+            int buf = 0;
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += GROUP) {
+                if (j + GROUP < kRadix) {
+                    issue(buf ^ 1, j + GROUP);  // next group flies while this one is reduced
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GROUP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) {
+                    const double2 va = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 0) * GROUP + u) * 1024 + lane * 16);
+                    const double2 vb = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 1) * GROUP + u) * 1024 + lane * 16);
+                    const double sa = wave_sum(va.x + va.y);
+                    const double sb = wave_sum(vb.x + vb.y);
+                    if (lane == j + u) { keep_a = sa; keep_b = sb; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot reads done before it is refilled
+                buf ^= 1;
+            }
+        } else {  // last, partial level-2 tile: guarded 8-byte loads through registers, zero fill
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
+                if (base + (uint64_t)j * kLeafF64 >= n) break;  // wave-uniform
+                const double a0 = i0 < n ? a[i0] : 0.0, a1 = i0 + 1 < n ? a[i0 + 1] : 0.0;
+                const double b0 = i0 < n ? b[i0] : 0.0, b1 = i0 + 1 < n ? b[i0 + 1] : 0.0;
+                const double sa = wave_sum(a0 + a1);
+                const double sb = wave_sum(b0 + b1);
+                if (lane == j) { keep_a = sa; keep_b = sb; }
+            }
+        }
+        l1[t * kRadix + lane] = NodeFst{keep_a, keep_b};
+        const double ta = wave_sum(keep_a), tb = wave_sum(keep_b);
+        if (lane == 0) l2[t] = NodeFst{ta, tb};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // BUILD, het: level-1 {nonmissing, nhet} per 1024 sites (16 int8 genotypes per lane).  1 B/site.
 // nonmissing = g >= 0, nhet = g == 1 (hetWindow.cpp:78-80), counted bytewise on packed words.
 // ------------------------------------------------------------------------------------------
@@ -697,6 +771,18 @@ inline BuildTuning build_tuning() {
     return t;
 }
 
+template <int GROUP>
+void launch_lds(dim3 grid, hipStream_t s, const PairCols &cols, uint64_t n, uint64_t n_l2, const TreeView &tv) {
+    constexpr size_t kShmem = 4 * (2 * 2 * GROUP * 1024);  // 4 waves per workgroup
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fst_build_lds_kernel<GROUP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShmem);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((fst_build_lds_kernel<GROUP>), grid, dim3(256), kShmem, s, cols, n, n_l2, tv);
+}
+
 inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
     // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
     // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
@@ -764,6 +850,14 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
             const BuildTuning bt = build_tuning();
             const dim3 grid(build_grid(tl.count[1], bt.blocks), np);
 #ifdef PGT_TUNING_BUILD  // tools/tune_build.py, tools/ablate_build.py: never defined in the product build
+            if (const char *e = std::getenv("PGT_TUNE_BUILD_LDS")) {
+                const int group = std::atoi(e);
+                const unsigned cap = bt.blocks ? bt.blocks : 2048;
+                const dim3 g2(build_grid(tl.count[1], cap), np);
+                if (group == 8) launch_lds<8>(g2, s, cols, n, tl.count[1], tv);
+                else if (group == 2) launch_lds<2>(g2, s, cols, n, tl.count[1], tv);
+                else launch_lds<4>(g2, s, cols, n, tl.count[1], tv);
+            } else
             if (std::getenv("PGT_TUNE_BUILD_ABLATE"))
                 hipLaunchKernelGGL((fst_build_kernel<4, true, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
             else if (bt.unroll == 8 && bt.nt)

@@ -77,6 +77,70 @@ __global__ __launch_bounds__(256) void probe(const double2 *__restrict__ a, cons
     if (acc == 123.456) sink[0] = acc;  // keep the loads alive
 }
 
+// MODE L: LDS-DMA.  Each wave owns 64-KiB chunks like MODE 0 but brings every 1-KiB piece into
+// its private LDS ring with global_load_lds_dwordx4 (no VGPR destination), then reads its own 16
+// bytes back with ds_read_b128.  GROUP pieces per column are in flight per wave (2*GROUP KiB),
+// two groups double-buffered.
+template <int GROUP, bool NT>
+__global__ __launch_bounds__(256) void probe_lds(const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                 size_t n2, double *sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    char *ring = lds + (size_t)wib * (2 * 2 * GROUP * 1024);  // [buf][col][piece] x 1 KiB
+    double acc = 0.0;
+    const size_t chunk = 4096;
+    constexpr int aux = NT ? 2 : 0;
+    for (size_t t = wave; t * chunk + chunk <= n2; t += n_waves) {
+        const double2 *pa = a + t * chunk, *pb = b + t * chunk;
+        auto issue = [&](int buf, int j) {
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+                __builtin_amdgcn_global_load_lds(pa + (j + u) * 64 + lane, (__attribute__((address_space(3))) void *)(ring + ((buf * 2 + 0) * GROUP + u) * 1024), 16, 0, aux);
+                __builtin_amdgcn_global_load_lds(pb + (j + u) * 64 + lane, (__attribute__((address_space(3))) void *)(ring + ((buf * 2 + 1) * GROUP + u) * 1024), 16, 0, aux);
+            }
+        };
+        issue(0, 0);
+        int buf = 0;
+#pragma unroll 1
+        for (int j = 0; j < 64; j += GROUP) {
+            if (j + GROUP < 64) {
+                issue(buf ^ 1, j + GROUP);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GROUP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+                const double2 va = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 0) * GROUP + u) * 1024 + lane * 16);
+                const double2 vb = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 1) * GROUP + u) * 1024 + lane * 16);
+                acc += va.x + va.y + vb.x + vb.y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ds_reads are done before the slot is refilled
+            buf ^= 1;
+        }
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+
+template <int GROUP, bool NT>
+double run_lds(const double2 *a, const double2 *b, size_t n2, double *sink, int blocks, int reps) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const size_t shmem = 4 * (2 * 2 * GROUP * 1024);
+    CK(hipFuncSetAttribute((const void *)probe_lds<GROUP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 2; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((probe_lds<GROUP, NT>), dim3(blocks), dim3(256), shmem, 0, a, b, n2, sink);
+        CK(hipGetLastError());
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1)); if (r >= 2) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
 template <int MODE, int UNROLL, bool NT, bool TWO>
 double run(const double2 *a, const double2 *b, size_t n2, double *sink, int blocks, int reps) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -115,6 +179,10 @@ int main() {
         ROW(3, 4, true, true, 4096, "block-owned 128 KiB tiles, 4 KiB pieces")
         ROW(3, 8, true, true, 2048, "block-owned 128 KiB tiles, 4 KiB pieces")
         ROW(3, 4, true, true, 8192, "block-owned 128 KiB tiles, 4 KiB pieces")
+#define ROWL(GROUP, NT, BL) { double t = run_lds<GROUP, NT>(a, b, n2, sink, BL, 9); \
+    printf("| LDS-DMA ring, wave-private chunks | %d | %d | 2 | %d | %.4f | %.0f |\n", 2 * GROUP, (int)NT, BL, t, gb2 / t * 1e3); }
+        ROWL(4, false, 512) ROWL(4, true, 512) ROWL(4, true, 1024) ROWL(4, true, 2048)
+        ROWL(2, true, 1280) ROWL(2, true, 2048) ROWL(8, true, 512)
         ROW(0, 8, true, false, 2048, "wave-private, ONE column")
         ROW(1, 8, true, false, 2048, "wave-interleaved, ONE column")
         ROW(2, 8, true, false, 2048, "block-contiguous, ONE column")
