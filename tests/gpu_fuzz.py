@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle fuzzer over every statistic (fst, het, dxy fixed-site and bp, extreme
 scores, AF front end), random sizes 1..2.5e6 and window geometries (including windows longer than
-level-3 tree nodes).  usage: python tools/gpu_fuzz.py [seconds] [seed]"""
+level-3 tree nodes).  usage: python tests/gpu_fuzz.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this script lives in tests/: it uses the oracle
 import oracle_bind  # noqa: E402
 import synth  # noqa: E402
 import popgenomicstools_amd as pgt  # noqa: E402

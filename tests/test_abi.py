@@ -90,3 +90,17 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "1 <= step <= window" in r.stdout
+
+
+def test_only_tests_smoke_and_bench_touch_the_oracle():
+    """oracle/ is the checker: nothing outside tests/, __graft_entry__.smoke() and bench.py's
+    cpu_baseline leg may import or execute it (tools/ included)."""
+    for base in ("tools", "popgenomicstools_amd", "include"):
+        for root, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+                    text = open(os.path.join(root, f), errors="ignore").read()
+                    assert "oracle_bind" not in text and "liboracle" not in text and "window_oracle" not in text, os.path.join(root, f)
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench_src.count("import oracle_bind") == 1 and "def cpu_baseline" in bench_src
+    assert bench_src.index("import oracle_bind") > bench_src.index("def cpu_baseline")
