@@ -84,11 +84,25 @@ struct TreeView {
 // ------------------------------------------------------------------------------------------
 // BUILD, fst: level-1 {Σa,Σb} per 128 sites, level-2 per 8192 sites.        16 B/site read.
 // grid.x: waves stride over level-2 tiles; grid.y: population pair.
+//
+// Node stores are DEFERRED.  Measured on the first version of this kernel, which stored a tile's 64
+// level-1 nodes as soon as the tile was done: removing that store made the kernel 7-10 % faster
+// although it is 0.8 % of the bytes (profiles/r01/ablate_stores.txt).  It is not a wave stall (a
+// dedicated store wave, and software pipelining across tiles, changed nothing); the explanation that
+// fits is on the memory side: L2 is write-through, so each node row reaches the DRAM channels as
+// isolated writes among ~300 reads, each paying a bus turnaround.  So a wave parks its finished
+// tiles' node rows in LDS (STAGE tiles = STAGE KiB per wave) and writes them out only when the stage
+// is full or its work is done; all waves progress in near lockstep, hence the whole chip flushes at
+// about the same times and the memory controllers see dense write bursts: +3.4 ... +8.6 % across boxes
+// and sizes, results bit for bit the same.  The stage is private to the wave: no barrier.
 // ------------------------------------------------------------------------------------------
-template <int UNROLL, bool NT, bool ABLATE_XLANE = false>
-__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2,
-                                                        TreeView tv) {
-    const int lane = threadIdx.x & (kWave - 1);
+constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
+constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
+constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
+template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>
+__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
+    extern __shared__ __attribute__((aligned(16))) char lds_stage[];
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const double *__restrict__ a = cols.a[blockIdx.y];
@@ -96,8 +110,27 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
     char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
     NodeFst *__restrict__ l1 = reinterpret_cast<NodeFst *>(tree + tv.off[0]);
     NodeFst *__restrict__ l2 = reinterpret_cast<NodeFst *>(tree + tv.off[1]);
-    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;  // 8192 sites
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+    NodeFst *stage = reinterpret_cast<NodeFst *>(lds_stage) + (size_t)wib * STAGE * kWave;  // [STAGE][64] per wave
 
+    int held = 0;
+    uint64_t first_t = 0;  // tile index of stage row 0; row k holds tile first_t + k * n_waves
+    auto flush = [&]() {
+        for (int k = 0; k < held; ++k) {
+            const uint64_t t = first_t + (uint64_t)k * n_waves;
+            const NodeFst v = stage[k * kWave + lane];
+            if constexpr (NT_STORE) {
+                double *q = reinterpret_cast<double *>(&l1[t * kRadix + lane]);
+                __builtin_nontemporal_store(v.x, q);
+                __builtin_nontemporal_store(v.y, q + 1);
+            } else {
+                l1[t * kRadix + lane] = v;
+            }
+            const double ta = wave_sum(v.x), tb = wave_sum(v.y);
+            if (lane == 0) l2[t] = NodeFst{ta, tb};
+        }
+        held = 0;
+    };
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
         double keep_a = 0.0, keep_b = 0.0;
@@ -108,97 +141,18 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
             for (int j = 0; j < kRadix; j += UNROLL) {
                 double2 va[UNROLL], vb[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {  // 2*UNROLL x 16-byte loads in flight per lane
-                    va[u] = load16<NT>(pa + (j + u) * kWave + lane);
-                    vb[u] = load16<NT>(pb + (j + u) * kWave + lane);
+                for (int u = 0; u < UNROLL; ++u) {
+                    va[u] = load16<true>(pa + (j + u) * kWave + lane);
+                    vb[u] = load16<true>(pb + (j + u) * kWave + lane);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    if constexpr (ABLATE_XLANE) {  // timing-only build: wrong results, same loads
-                        keep_a += va[u].x + va[u].y;
-                        keep_b += vb[u].x + vb[u].y;
-                    } else {
-                        const double sa = wave_sum(va[u].x + va[u].y);
-                        const double sb = wave_sum(vb[u].x + vb[u].y);
-                        if (lane == j + u) { keep_a = sa; keep_b = sb; }
-                    }
-                }
-            }
-        } else {  // last, partial level-2 tile: guarded 8-byte loads, zero fill
-            for (int j = 0; j < kRadix; ++j) {
-                const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
-                if (base + (uint64_t)j * kLeafF64 >= n) break;  // wave-uniform
-                const double a0 = i0 < n ? a[i0] : 0.0, a1 = i0 + 1 < n ? a[i0 + 1] : 0.0;
-                const double b0 = i0 < n ? b[i0] : 0.0, b1 = i0 + 1 < n ? b[i0 + 1] : 0.0;
-                const double sa = wave_sum(a0 + a1);
-                const double sb = wave_sum(b0 + b1);
-                if (lane == j) { keep_a = sa; keep_b = sb; }
-            }
-        }
-        l1[t * kRadix + lane] = NodeFst{keep_a, keep_b};  // one 1-KiB coalesced wave store
-        const double ta = wave_sum(keep_a), tb = wave_sum(keep_b);
-        if (lane == 0) l2[t] = NodeFst{ta, tb};
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// BUILD, fst, LDS-DMA form: the same tiles, sums and node layout as fst_build_kernel, but each 1-KiB
-// piece goes global -> LDS directly (global_load_lds_dwordx4 ... nt, no VGPR destination) into a
-// ring private to the wave, which then reads its own 16 bytes back (ds_read_b128).  A load-only
-// probe streams 6.7 TB/s this way against 6.4 TB/s through registers (profiles/r01/stream_probe.md).
-// No barrier: a wave only ever reads what it loaded itself; the DMA is ordered by vmcnt.
-// Ring = 2 buffers x 2 columns x GROUP pieces of 1 KiB per wave.
-// ------------------------------------------------------------------------------------------
-template <int GROUP>
-__global__ __launch_bounds__(256) void fst_build_lds_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
-    extern __shared__ __attribute__((aligned(16))) char lds_ring[];
-    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const double *__restrict__ a = cols.a[blockIdx.y];
-    const double *__restrict__ b = cols.b[blockIdx.y];
-    char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
-    NodeFst *__restrict__ l1 = reinterpret_cast<NodeFst *>(tree + tv.off[0]);
-    NodeFst *__restrict__ l2 = reinterpret_cast<NodeFst *>(tree + tv.off[1]);
-    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
-    char *ring = lds_ring + (size_t)wib * (2 * 2 * GROUP * 1024);
-    using lds_ptr = __attribute__((address_space(3))) void *;
-
-    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
-        const uint64_t base = t * kTile2;
-        double keep_a = 0.0, keep_b = 0.0;
-        if (base + kTile2 <= n) {
-            const double2 *pa = reinterpret_cast<const double2 *>(a + base);
-            const double2 *pb = reinterpret_cast<const double2 *>(b + base);
-            auto issue = [&](int buf, int j) {
-#pragma unroll
-                for (int u = 0; u < GROUP; ++u) {
-                    __builtin_amdgcn_global_load_lds(pa + (j + u) * kWave + lane, (lds_ptr)(ring + ((buf * 2 + 0) * GROUP + u) * 1024), 16, 0, 2);
-                    __builtin_amdgcn_global_load_lds(pb + (j + u) * kWave + lane, (lds_ptr)(ring + ((buf * 2 + 1) * GROUP + u) * 1024), 16, 0, 2);
-                }
-            };
-            issue(0, 0);
-            int buf = 0;
-#pragma unroll 1
-            for (int j = 0; j < kRadix; j += GROUP) {
-                if (j + GROUP < kRadix) {
-                    issue(buf ^ 1, j + GROUP);  // next group flies while this one is reduced
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GROUP) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-#pragma unroll
-                for (int u = 0; u < GROUP; ++u) {
-                    const double2 va = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 0) * GROUP + u) * 1024 + lane * 16);
-                    const double2 vb = *reinterpret_cast<const double2 *>(ring + ((buf * 2 + 1) * GROUP + u) * 1024 + lane * 16);
-                    const double sa = wave_sum(va.x + va.y);
-                    const double sb = wave_sum(vb.x + vb.y);
+                    const double sa = wave_sum(va[u].x + va[u].y);
+                    const double sb = wave_sum(vb[u].x + vb[u].y);
                     if (lane == j + u) { keep_a = sa; keep_b = sb; }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot reads done before it is refilled
-                buf ^= 1;
             }
-        } else {  // last, partial level-2 tile: guarded 8-byte loads through registers, zero fill
+        } else {
             for (int j = 0; j < kRadix; ++j) {
                 const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
                 if (base + (uint64_t)j * kLeafF64 >= n) break;  // wave-uniform
@@ -209,10 +163,11 @@ __global__ __launch_bounds__(256) void fst_build_lds_kernel(PairCols cols, uint6
                 if (lane == j) { keep_a = sa; keep_b = sb; }
             }
         }
-        l1[t * kRadix + lane] = NodeFst{keep_a, keep_b};
-        const double ta = wave_sum(keep_a), tb = wave_sum(keep_b);
-        if (lane == 0) l2[t] = NodeFst{ta, tb};
+        if (held == 0) first_t = t;
+        stage[held * kWave + lane] = NodeFst{keep_a, keep_b};  // the wave's own LDS rows: no barrier needed
+        if (++held == STAGE) flush();
     }
+    flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,36 +708,6 @@ inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     return PGT_EDEVICE;
 }
 
-// Launch geometry of the build kernels: 2048 workgroups (8 per CU), 4 leaf tiles per loop iteration
-// (8 x 16-byte loads in flight per lane), non-temporal loads — chosen by interleaved A/B runs on
-// MI355X (profiles/r01/tune_build.md).  The alternatives are only compiled with -DPGT_TUNING_BUILD.
-struct BuildTuning {
-    unsigned blocks;  // workgroup cap; waves grid-stride over level-2 tiles beyond it (0 = no cap)
-    int unroll;       // leaf tiles per loop iteration: 2*unroll 16-byte loads in flight per lane
-    bool nt;          // non-temporal column loads
-};
-inline BuildTuning build_tuning() {
-    BuildTuning t{2048u, 4, true};
-#ifdef PGT_TUNING_BUILD
-    if (const char *e = std::getenv("PGT_TUNE_BUILD_BLOCKS")) t.blocks = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("PGT_TUNE_BUILD_UNROLL")) t.unroll = std::atoi(e);
-    if (const char *e = std::getenv("PGT_TUNE_BUILD_NT")) t.nt = std::atoi(e) != 0;
-#endif
-    return t;
-}
-
-template <int GROUP>
-void launch_lds(dim3 grid, hipStream_t s, const PairCols &cols, uint64_t n, uint64_t n_l2, const TreeView &tv) {
-    constexpr size_t kShmem = 4 * (2 * 2 * GROUP * 1024);  // 4 waves per workgroup
-    static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fst_build_lds_kernel<GROUP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShmem);
-        return true;
-    }();
-    (void)once;
-    hipLaunchKernelGGL((fst_build_lds_kernel<GROUP>), grid, dim3(256), kShmem, s, cols, n, n_l2, tv);
-}
-
 inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
     // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
     // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
@@ -832,6 +757,10 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
     return hip_fail(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord", err);
 }
 
+#ifdef PGT_TUNING_BUILD
+#include "pgt_build_experiments.inc"
+#endif
+
 }  // namespace
 
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
@@ -847,28 +776,19 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes, levels);
         if (p0 == 0) if (int rc = record(ev_build0, s, err)) return rc;
         if (n > 0) {
-            const BuildTuning bt = build_tuning();
-            const dim3 grid(build_grid(tl.count[1], bt.blocks), np);
-#ifdef PGT_TUNING_BUILD  // tools/tune_build.py, tools/ablate_build.py: never defined in the product build
-            if (const char *e = std::getenv("PGT_TUNE_BUILD_LDS")) {
-                const int group = std::atoi(e);
-                const unsigned cap = bt.blocks ? bt.blocks : 2048;
-                const dim3 g2(build_grid(tl.count[1], cap), np);
-                if (group == 8) launch_lds<8>(g2, s, cols, n, tl.count[1], tv);
-                else if (group == 2) launch_lds<2>(g2, s, cols, n, tl.count[1], tv);
-                else launch_lds<4>(g2, s, cols, n, tl.count[1], tv);
-            } else
-            if (std::getenv("PGT_TUNE_BUILD_ABLATE"))
-                hipLaunchKernelGGL((fst_build_kernel<4, true, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else if (bt.unroll == 8 && bt.nt)
-                hipLaunchKernelGGL((fst_build_kernel<8, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else if (bt.unroll == 8)
-                hipLaunchKernelGGL((fst_build_kernel<8, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else if (!bt.nt)
-                hipLaunchKernelGGL((fst_build_kernel<4, false>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
-            else
+            bool launched = false;
+#ifdef PGT_TUNING_BUILD  // tools/tune_*.py, tools/ablate_*.py: never defined in the product build
+            launched = launch_fst_experiment(s, cols, np, n, tl, tv);
 #endif
-                hipLaunchKernelGGL((fst_build_kernel<4, true>), grid, dim3(256), 0, s, cols, n, tl.count[1], tv);
+            if (!launched) {
+                static const bool lds_ok = [] {  // 64 KiB of dynamic LDS per workgroup: declare it once
+                    return hipFuncSetAttribute(reinterpret_cast<const void *>(fst_build_kernel<>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes) == hipSuccess;
+                }();
+                (void)lds_ok;
+                hipLaunchKernelGGL((fst_build_kernel<>), dim3(build_grid(tl.count[1], kFstBuildBlocks), np), dim3(256),
+                                   kFstStageBytes, s, cols, n, tl.count[1], tv);
+            }
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
         }

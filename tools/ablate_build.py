@@ -18,6 +18,7 @@ ctx = pgt.Context(0)
 tree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
 ctx.set_profiling(True)
 os.environ["PGT_TUNE_BUILD_NT"] = "1"
+os.environ["PGT_TUNE_BUILD_STRAIGHT"] = "1"  # the ablation applies to the straight (first) kernel
 for m, chroms in ((1_000_000_000, 40), (100_000_000, 20)):
     rl = np.full(chroms, m // chroms, dtype=np.uint64)
     win = windows_to_device(pgt.build_windows_sites(rl, 50_000, 10_000), dev)

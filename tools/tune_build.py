@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of fst_build_kernel variants in ONE process (cdna_hip_programming.md §5.4 rule 24).
+"""Interleaved A/B of the straight build kernel's knobs (fst_build_straight_kernel) in ONE process (cdna_hip_programming.md §5.4 rule 24).
 
 Variants are selected through the PGT_TUNE_BUILD_* environment variables that csrc/pgt_kernels.hip
 reads at launch time.  Prints median / min kernel time (HIP events around the build pass) per
@@ -42,6 +42,7 @@ def main():
     for r in range(rounds + 1):
         for m, (win, out) in sizes.items():
             for i, v in enumerate(variants):
+                os.environ["PGT_TUNE_BUILD_STRAIGHT"] = "1"  # these knobs belong to the straight (first) kernel
                 os.environ["PGT_TUNE_BUILD_BLOCKS"] = str(v["blocks"])
                 os.environ["PGT_TUNE_BUILD_UNROLL"] = str(v["unroll"])
                 os.environ["PGT_TUNE_BUILD_NT"] = str(v["nt"])

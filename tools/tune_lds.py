@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B: fst_build_kernel (register loads) vs fst_build_lds_kernel (LDS-DMA ring) in one
+"""Interleaved A/B: fst_build_straight_kernel (register loads) vs fst_build_lds_kernel (LDS-DMA ring) in one
 process; also checks that both produce the same bytes.  Needs a library built with -DPGT_TUNING_BUILD
 (PGT_EXTRA_HIPCC_FLAGS=-DPGT_TUNING_BUILD python -m popgenomicstools_amd.build --force)."""
 import os
@@ -30,12 +30,25 @@ def main():
         win = windows_to_device(pgt.build_windows_sites(rl, 50_000, 10_000), dev)
         out = torch.empty(win.numel() // 32 * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         sizes[m] = (win, out)
-    variants = [("registers (product)", None, None)] + [(f"LDS-DMA ring, {2 * g} loads in flight", g, bl)
-                                                        for g, bl in ((2, 1280), (4, 512), (4, 1024), (4, 2048), (8, 256), (8, 512))]
+    variants = [("straight kernel, register loads", "straight", None), ("straight kernel, permlane-swap butterfly", "perm", None)] + [(f"LDS-DMA ring, {2 * g} loads in flight", g, bl)
+                                                        for g, bl in ((4, 1024), (4, 2048))] + [
+        ("LDS-DMA ring, 8 loads in flight, permlane-swap butterfly", "ldsperm", 1024),
+        ("LDS-DMA ring, 8 loads in flight, permlane-swap butterfly", "ldsperm", 2048)]
     def select(v):
         os.environ.pop("PGT_TUNE_BUILD_LDS", None)
         os.environ.pop("PGT_TUNE_BUILD_BLOCKS", None)
-        if v[1] is not None:
+        os.environ.pop("PGT_TUNE_BUILD_PERMLANE", None)
+        os.environ.pop("PGT_TUNE_BUILD_STRAIGHT", None)
+        if v[1] == "straight":
+            os.environ["PGT_TUNE_BUILD_STRAIGHT"] = "1"
+        elif v[1] == "perm":
+            os.environ["PGT_TUNE_BUILD_STRAIGHT"] = "1"
+            os.environ["PGT_TUNE_BUILD_PERMLANE"] = "1"
+        elif v[1] == "ldsperm":
+            os.environ["PGT_TUNE_BUILD_PERMLANE"] = "1"
+            os.environ["PGT_TUNE_BUILD_LDS"] = "4"
+            os.environ["PGT_TUNE_BUILD_BLOCKS"] = str(v[2])
+        elif v[1] is not None:
             os.environ["PGT_TUNE_BUILD_LDS"] = str(v[1])
             os.environ["PGT_TUNE_BUILD_BLOCKS"] = str(v[2])
     # correctness first: same bytes
