@@ -99,6 +99,42 @@ struct TreeView {
 constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
+
+// The per-wave LDS stage shared by the fst, dxy and extreme-score builds (16-byte nodes: 1 KiB per row).
+template <class Node>
+__device__ __forceinline__ void store_node_nt(Node *dst, const Node &v) {
+    static_assert(sizeof(Node) == 16, "16-byte nodes");
+    double w[2];
+    __builtin_memcpy(w, &v, 16);
+    double *q = reinterpret_cast<double *>(dst);
+    __builtin_nontemporal_store(w[0], q);
+    __builtin_nontemporal_store(w[1], q + 1);
+}
+template <class Node, int STAGE, bool NT_STORE>
+struct NodeStage {
+    Node *rows;  // LDS: [STAGE][64] of this wave
+    Node *l1, *l2;
+    uint64_t n_waves, first_t = 0;  // row k holds tile first_t + k * n_waves
+    int lane, held = 0;
+    __device__ __forceinline__ NodeStage(char *lds, int wib, int lane_, Node *l1_, Node *l2_, uint64_t n_waves_)
+        : rows(reinterpret_cast<Node *>(lds) + (size_t)wib * STAGE * kWave), l1(l1_), l2(l2_), n_waves(n_waves_), lane(lane_) {}
+    __device__ __forceinline__ void flush() {
+        for (int k = 0; k < held; ++k) {
+            const uint64_t t = first_t + (uint64_t)k * n_waves;
+            const Node v = rows[k * kWave + lane];
+            if constexpr (NT_STORE) store_node_nt(&l1[t * kRadix + lane], v);
+            else l1[t * kRadix + lane] = v;  // one 1-KiB coalesced wave store
+            const Node top = node_wave_sum(v);
+            if (lane == 0) l2[t] = top;
+        }
+        held = 0;
+    }
+    __device__ __forceinline__ void put(uint64_t t, const Node &keep) {  // lane j holds the node of leaf tile j
+        if (held == 0) first_t = t;
+        rows[held * kWave + lane] = keep;  // the wave's own LDS rows: no barrier needed
+        if (++held == STAGE) flush();
+    }
+};
 template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>
 __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
@@ -111,26 +147,8 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
     NodeFst *__restrict__ l1 = reinterpret_cast<NodeFst *>(tree + tv.off[0]);
     NodeFst *__restrict__ l2 = reinterpret_cast<NodeFst *>(tree + tv.off[1]);
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
-    NodeFst *stage = reinterpret_cast<NodeFst *>(lds_stage) + (size_t)wib * STAGE * kWave;  // [STAGE][64] per wave
+    NodeStage<NodeFst, STAGE, NT_STORE> stage(lds_stage, wib, lane, l1, l2, n_waves);
 
-    int held = 0;
-    uint64_t first_t = 0;  // tile index of stage row 0; row k holds tile first_t + k * n_waves
-    auto flush = [&]() {
-        for (int k = 0; k < held; ++k) {
-            const uint64_t t = first_t + (uint64_t)k * n_waves;
-            const NodeFst v = stage[k * kWave + lane];
-            if constexpr (NT_STORE) {
-                double *q = reinterpret_cast<double *>(&l1[t * kRadix + lane]);
-                __builtin_nontemporal_store(v.x, q);
-                __builtin_nontemporal_store(v.y, q + 1);
-            } else {
-                l1[t * kRadix + lane] = v;
-            }
-            const double ta = wave_sum(v.x), tb = wave_sum(v.y);
-            if (lane == 0) l2[t] = NodeFst{ta, tb};
-        }
-        held = 0;
-    };
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
         double keep_a = 0.0, keep_b = 0.0;
@@ -163,11 +181,9 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
                 if (lane == j) { keep_a = sa; keep_b = sb; }
             }
         }
-        if (held == 0) first_t = t;
-        stage[held * kWave + lane] = NodeFst{keep_a, keep_b};  // the wave's own LDS rows: no barrier needed
-        if (++held == STAGE) flush();
+        stage.put(t, NodeFst{keep_a, keep_b});
     }
-    flush();
+    stage.flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,13 +270,14 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
 
 __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, const double *__restrict__ p2,
                                                const int32_t *__restrict__ n1, const int32_t *__restrict__ n2,
-                                               uint64_t n, int minind, uint64_t n_l2, const TreeView &tv) {
+                                               uint64_t n, int minind, uint64_t n_l2, const TreeView &tv, char *lds_stage) {
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     NodeDxy *__restrict__ l1 = reinterpret_cast<NodeDxy *>(tv.base + tv.off[0]);
     NodeDxy *__restrict__ l2 = reinterpret_cast<NodeDxy *>(tv.base + tv.off[1]);
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
+    NodeStage<NodeDxy, kFstStage, true> stage(lds_stage, threadIdx.x >> 6, lane, l1, l2, n_waves);  // deferred node stores
 
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
@@ -303,16 +320,16 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
                 if (lane == j) keep = acc;
             }
         }
-        l1[t * kRadix + lane] = keep;
-        const NodeDxy tot = node_wave_sum(keep);
-        if (lane == 0) l2[t] = tot;
+        stage.put(t, keep);
     }
+    stage.flush();
 }
 
 __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const double *p2, const int32_t *n1,
                                                         const int32_t *n2, uint64_t n, int minind, uint64_t n_l2,
                                                         TreeView tv) {
-    dxy_build_body(p1, p2, n1, n2, n, minind, n_l2, tv);
+    extern __shared__ __attribute__((aligned(16))) char lds_stage[];
+    dxy_build_body(p1, p2, n1, n2, n, minind, n_l2, tv, lds_stage);
 }
 
 // BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
@@ -328,7 +345,8 @@ struct DxyHetBuildArgs {
     TreeView tv_dxy, tv_het[2];
 };
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
-    if (blockIdx.y == 0) dxy_build_body(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy);
+    extern __shared__ __attribute__((aligned(16))) char lds_stage[];
+    if (blockIdx.y == 0) dxy_build_body(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy, lds_stage);
     else het_build_body(f.g[blockIdx.y - 1], f.n, f.n_items_het, f.tv_het[blockIdx.y - 1]);
 }
 
@@ -520,6 +538,9 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t
     NodeExt *__restrict__ l1 = reinterpret_cast<NodeExt *>(tv.base + tv.off[0]);
     NodeExt *__restrict__ l2 = reinterpret_cast<NodeExt *>(tv.base + tv.off[1]);
     constexpr uint64_t kTile2 = (uint64_t)kLeafExt * kRadix;  // 16384 sites
+    // Node stores are NOT deferred here: this kernel spends more instructions per byte (argmax combine
+    // over three fields) and needs the full 32 waves per CU; with the 64-KiB stage (8 waves per CU) it
+    // fell from 69 % to 60 % of the HBM peak (profiles/r01/measure_configs_1e9.md history).
     auto site = [&](double s, uint64_t i) {
         const double k = ExtTraits::key_of(s, g.mode);
         return NodeExt{k, (uint32_t)i, (uint32_t)(k > g.thr)};
@@ -708,6 +729,14 @@ inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     return PGT_EDEVICE;
 }
 
+// 64 KiB of dynamic LDS per workgroup for the node stage: declared once per kernel
+template <auto Kernel>  // one static per kernel (a type parameter would be shared by kernels of equal signature)
+void allow_stage_lds() {
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes);
+    (void)once;
+}
+
 inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
     // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
     // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
@@ -781,11 +810,7 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
             launched = launch_fst_experiment(s, cols, np, n, tl, tv);
 #endif
             if (!launched) {
-                static const bool lds_ok = [] {  // 64 KiB of dynamic LDS per workgroup: declare it once
-                    return hipFuncSetAttribute(reinterpret_cast<const void *>(fst_build_kernel<>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes) == hipSuccess;
-                }();
-                (void)lds_ok;
+                allow_stage_lds<fst_build_kernel<>>();
                 hipLaunchKernelGGL((fst_build_kernel<>), dim3(build_grid(tl.count[1], kFstBuildBlocks), np), dim3(256),
                                    kFstStageBytes, s, cols, n, tl.count[1], tv);
             }
@@ -836,7 +861,8 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s, p1, p2, n1, n2, n,
+        allow_stage_lds<dxy_build_kernel>();
+        hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1], kFstBuildBlocks)), dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n,
                            minind, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(tl, tv, 1, s, err)) return rc;
@@ -892,7 +918,8 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         const uint64_t n_items = het_items(n);
         DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], n_items, tvd, {tvh0, tvh1}};
         const uint64_t tiles = td.count[1] > n_items ? td.count[1] : n_items;
-        hipLaunchKernelGGL(dxy_het_build_kernel, dim3(build_grid(tiles), 3), dim3(256), 0, s, f);
+        allow_stage_lds<dxy_het_build_kernel>();
+        hipLaunchKernelGGL(dxy_het_build_kernel, dim3(build_grid(tiles, kFstBuildBlocks), 3), dim3(256), kFstStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
         if (int rc = launch_upper<NodeHet>(th, tvh0, 1, s, err, 1, n_items * kHetChunk)) return rc;
