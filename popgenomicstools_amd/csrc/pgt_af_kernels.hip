@@ -305,9 +305,6 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         uint64_t blocks = (tl.count[1] + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kWave * sizeof(double);  // 4 waves x V rows x 512 B
-        static const hipError_t lds_once = hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStage);
-        (void)lds_once;
         hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
         for (int k = 2; k < tv.n_levels; ++k) {
@@ -329,6 +326,19 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
 }
 
 }  // namespace
+
+namespace {
+template <int NP>
+void af_allow_lds() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)4 * Shape<NP>::kVals * kWave * sizeof(double)));
+}
+}  // namespace
+
+int init_af_kernels(std::string *err) {
+    af_allow_lds<2>(); af_allow_lds<3>(); af_allow_lds<4>(); af_allow_lds<5>(); af_allow_lds<6>(); af_allow_lds<7>(); af_allow_lds<8>();
+    return hip_fail(hipGetLastError(), "hipFuncSetAttribute", err);
+}
 
 int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops, uint64_t n,
                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream, void *ev_build0,

@@ -128,6 +128,11 @@ pgt_ctx *pgt_open(int device) {
         set_global_error(std::string("pgt_open: hipSetDevice: ") + hipGetErrorString(e));
         return nullptr;
     }
+    std::string init_err;
+    if (init_kernels(&init_err) != PGT_OK || init_af_kernels(&init_err) != PGT_OK) {
+        set_global_error("pgt_open: " + init_err);
+        return nullptr;
+    }
     pgt_ctx *ctx = new pgt_ctx;
     ctx->device = device;
     for (auto &ev : ctx->ev)

@@ -131,6 +131,9 @@ int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *
                   uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
 
+int init_kernels(std::string *err);     // pgt_kernels.hip: one-time kernel attributes (called by pgt_open)
+int init_af_kernels(std::string *err);  // pgt_af_kernels.hip
+
 // thread-local message for the ctx-less entry points
 void set_global_error(const std::string &msg);
 const std::string &global_error();

@@ -792,6 +792,15 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 
 }  // namespace
 
+// Called once from pgt_open: declares the dynamic-LDS needs of the staged build kernels, so that no
+// attribute call can fall inside a caller's stream capture.
+int init_kernels(std::string *err) {
+    allow_stage_lds<fst_build_kernel<>>();
+    allow_stage_lds<dxy_build_kernel>();
+    allow_stage_lds<dxy_het_build_kernel>();
+    return hip_fail(hipGetLastError(), "hipFuncSetAttribute", err);
+}
+
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
                void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window) {
