@@ -794,11 +794,14 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 
 // Called once from pgt_open: declares the dynamic-LDS needs of the staged build kernels, so that no
 // attribute call can fall inside a caller's stream capture.
-int init_kernels(std::string *err) {
-    allow_stage_lds<fst_build_kernel<>>();
-    allow_stage_lds<dxy_build_kernel>();
-    allow_stage_lds<dxy_het_build_kernel>();
-    return hip_fail(hipGetLastError(), "hipFuncSetAttribute", err);
+int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function attributes are per device
+    const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>), reinterpret_cast<const void *>(dxy_build_kernel),
+                            reinterpret_cast<const void *>(dxy_het_build_kernel)};
+    for (const void *k : staged)
+        if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
+                              "hipFuncSetAttribute", err))
+            return rc;
+    return PGT_OK;
 }
 
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
