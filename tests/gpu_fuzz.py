@@ -32,8 +32,12 @@ def main():
     t0 = time.time()
     counts = {}
     trial = 0
+    last_note = t0
     while time.time() - t0 < budget:
         trial += 1
+        if time.time() - last_note > 30:  # keep a long run visibly alive
+            print(f"  ... {trial} trials, {time.time() - t0:.0f} s", flush=True)
+            last_note = time.time()
         kind = rng.choice(["fst", "het", "dxy_fixed", "dxy_bp", "ext", "af"])
         n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20_000), rng.integers(20_000, 400_000),
                             rng.integers(400_000, 2_500_000)], p=[0.25, 0.3, 0.3, 0.15]))
