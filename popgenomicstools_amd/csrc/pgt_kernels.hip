@@ -136,7 +136,7 @@ struct NodeStage {
     }
 };
 template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>
-__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
+__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv, uint64_t t_begin = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
     NodeStage<NodeFst, STAGE, NT_STORE> stage(lds_stage, wib, lane, l1, l2, n_waves);
 
-    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
+    for (uint64_t t = t_begin + wave0; t < n_l2; t += n_waves) {  // n_l2 is the end of this launch's tile range
         const uint64_t base = t * kTile2;
         double keep_a = 0.0, keep_b = 0.0;
         if (base + kTile2 <= n) {
@@ -824,7 +824,7 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
             if (!launched) {
                 allow_stage_lds<fst_build_kernel<>>();
                 hipLaunchKernelGGL((fst_build_kernel<>), dim3(build_grid(tl.count[1], kFstBuildBlocks), np), dim3(256),
-                                   kFstStageBytes, s, cols, n, tl.count[1], tv);
+                                   kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
             }
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;

@@ -17,11 +17,12 @@ import popgenomicstools_amd as pgt  # noqa: E402
 from popgenomicstools_amd._lib import FST_ROW_DTYPE, PGT_STAT_FST  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 
-ALL_ENVS = ("PGT_TUNE_BUILD_STRAIGHT", "PGT_TUNE_BUILD_BLOCKS", "PGT_TUNE_BUILD_STORE_MODE", "PGT_TUNE_BUILD_ABLATE", "PGT_TUNE_BUILD_PIPE", "PGT_TUNE_BUILD_SW",
+ALL_ENVS = ("PGT_TUNE_BUILD_PHASED", "PGT_TUNE_BUILD_STRAIGHT", "PGT_TUNE_BUILD_BLOCKS", "PGT_TUNE_BUILD_STORE_MODE", "PGT_TUNE_BUILD_ABLATE", "PGT_TUNE_BUILD_PIPE", "PGT_TUNE_BUILD_SW",
             "PGT_TUNE_BUILD_DEFER")
 ST = {"PGT_TUNE_BUILD_STRAIGHT": "1"}  # the first product kernel: node rows stored after every tile
 REAL = {  # variants that must reproduce the product's bytes
     "product: stores deferred, 16 tiles staged, nt, 512 WGs": {},
+    "product kernel, one launch per stage (4 launches at 1e9)": {"PGT_TUNE_BUILD_PHASED": "1"},
     "deferred: 16 staged, plain stores": {"PGT_TUNE_BUILD_DEFER": "16:4:0:512"},
     "deferred: 16 staged, 16+16 loads in flight": {"PGT_TUNE_BUILD_DEFER": "16:8:1:512"},
     "deferred: 32 staged, 256 WGs": {"PGT_TUNE_BUILD_DEFER": "32:4:1:256"},
