@@ -247,6 +247,8 @@ def main():
             "config": {"workload": f"fstWindow 2 pops x {n:.0e} sites per GPU in {args.chroms} chromosomes, "
                                    f"window {W} sites / step {S} sites, {win.size} windows per GPU, columns resident in HBM"
                                    + (", rows gathered to rank 0 over RCCL" if world > 1 else ""),
+                       "baseline_config": "the 10^9-site two-population FST window scan north_star's target is quoted on "
+                                          "(it fits one GPU: 20 GB); BASELINE configs[1] (10^8 sites) is measured with --extra",
                        "sites_per_gpu": n, "winsize": W, "stepsize": S, "windows_per_gpu": int(win.size),
                        "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
                                       if world > 1 else "single GPU"},
