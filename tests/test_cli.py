@@ -240,3 +240,34 @@ def test_extreme_cli_against_reference_goldens(hosts_ext, tmp_path):
         r = run(argv)
         assert r.returncode == 0, r.stderr
         assert r.stdout == c["stdout"], c["args"]  # selections and integer ratios: byte-identical
+
+
+@pytest.mark.gpu
+def test_cli_input_format_edge_cases(hosts, tmp_path):
+    """Text details: CRLF line ends, a last line without newline (the reference loops forever on it,
+    SURVEY Q8), exponent notation / leading '+', extra columns, and the stop at the first empty line
+    (fstWindow.cpp:125) all give the rows of the plain file."""
+    plain = "".join(f"c1\t{10 * i}\t{0.01 * i:.6f}\t0.2\n" for i in range(1, 9)) + "".join(f"c2\t{7 * i}\t0.05\t0.25\n" for i in range(1, 6))
+    f = tmp_path / "plain.txt"
+    f.write_text(plain)
+    ref = run([hosts["fstWindow"], str(f), "4", "2"])
+    assert ref.returncode == 0 and len(ref.stdout.splitlines()) >= 4
+    variants = {
+        "crlf": plain.replace("\n", "\r\n"),
+        "no_final_newline": plain.rstrip("\n"),
+        "exponent_and_plus": plain.replace("\t0.2\n", "\t+2e-1\n").replace("\t0.25\n", "\t2.5E-1\n"),
+        "extra_columns": plain.replace("\n", "\tignored\t1\n"),
+        "stops_at_empty_line": plain + "\nc9\t1\t0.5\t0.5\nc9\t2\t0.5\t0.5\nc9\t3\t0.5\t0.5\nc9\t4\t0.5\t0.5\nc9\t5\t0.5\t0.5\n",
+        "spaces_for_tabs": plain.replace("\t", "  "),
+    }
+    for name, text in variants.items():
+        p = tmp_path / f"{name}.txt"
+        p.write_bytes(text.encode())
+        r = run([hosts["fstWindow"], str(p), "4", "2"])
+        assert r.returncode == 0, (name, r.stderr)
+        assert r.stdout == ref.stdout, name
+    # gzip input is read transparently by every host (zlib), not only by dxyWindow
+    gz = tmp_path / "plain.txt.gz"
+    with gzip.open(gz, "wt") as fh:
+        fh.write(plain)
+    assert run([hosts["fstWindow"], str(gz), "4", "2"]).stdout == ref.stdout
