@@ -12,11 +12,13 @@
 //             exactly one 16-byte load per lane of a 64-lane wave),
 //   level k = one node per 64 level-(k-1) nodes (one lane per child).
 // BUILD is the only pass that streams the columns: one wave owns one level-2 tile (64 leaf
-// tiles), issues 16-byte loads only, reduces each leaf tile with a wave butterfly, parks the
-// leaf total in lane j, and at the end stores the 64 level-1 nodes with ONE coalesced 1-KiB
-// wave store plus one level-2 node.  No LDS, no barrier, no atomics: bitwise deterministic.
+// tiles), issues 16-byte non-temporal loads only, reduces each leaf tile with a wave butterfly and
+// parks the leaf total in lane j; the finished tile's 64 level-1 nodes go to a per-wave LDS stage
+// and reach HBM later as coalesced 1-KiB rows, all waves of the chip at about the same times
+// (deferred stores: node writes interleaved with the read stream cost 10x their byte share).
+// No barrier, no atomics: bitwise deterministic.
 // QUERY gives one wave per window: at each level the ragged left/right remainders (< radix
-// nodes each) are read lane-parallel, the aligned interior moves up a level.
+// nodes each) are read lane-parallel and loop-free, the aligned interior moves up a level.
 // Memory-bound: 2 f64 adds per 16 B, no contraction to feed MFMA (none is used).
 #include <hip/hip_runtime.h>
 
