@@ -153,13 +153,34 @@ def main():
     counts = [win.size] * world  # every rank has the same geometry
     gather = RowGatherer(counts, FST_ROW_DTYPE.itemsize, coll_dev, dst=0) if world > 1 else None
 
+    # Opt-in (PGT_BENCH_ASYNC_GATHER=1, never set by the driver): rows are double-buffered and the
+    # gather of step k is only waited for before step k+2 reuses its buffer, so it overlaps the build
+    # of step k+1.  Default: the gather completes inside the step that produced the rows.
+    async_gather = gather is not None and os.environ.get("PGT_BENCH_ASYNC_GATHER") == "1"
+    outs = [out, torch.empty_like(out)] if async_gather else [out]
+    pending = [None, None]
+    counter = [0]
+
     def step():
-        ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
-        if gather is not None:
-            return gather(out if coll_dev is dev else out.cpu())  # one RCCL gather of 40 B/window to rank 0
-        return out
+        k = counter[0] & 1 if async_gather else 0
+        counter[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()  # the gather that last read outs[k] must be done before it is overwritten
+            pending[k] = None
+        ctx.fst_reduce_dev(pos, a, b, win_d, out=outs[k], tree=tree)
+        if gather is None:
+            return outs[k]
+        rows = outs[k] if coll_dev is dev else outs[k].cpu()
+        if async_gather:
+            pending[k] = (gather.start(rows), rows)[0]
+            return None
+        return gather(rows)  # one RCCL gather of 40 B/window to rank 0
 
     def fence():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -250,7 +271,8 @@ def main():
                        "baseline_config": "the 10^9-site two-population FST window scan north_star's target is quoted on "
                                           "(it fits one GPU: 20 GB); BASELINE configs[1] (10^8 sites) is measured with --extra",
                        "sites_per_gpu": n, "winsize": W, "stepsize": S, "windows_per_gpu": int(win.size),
-                       "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
+                       "parallelism": (f"site-range shards x{world}" + (", async gather" if async_gather else "")
+                                       + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "fst_build_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),

@@ -43,6 +43,17 @@ class RowGatherer:
         self.recv = ([torch.empty(self.width, dtype=torch.uint8, device=device) for _ in range(self.world)]
                      if self.rank == dst else None)
 
+    def start(self, local_rows):
+        """Asynchronous form: issues the gather and returns its Work handle; the caller must keep
+        `local_rows` untouched until handle.wait() (a stream-level wait) has been issued.  Lets the
+        gather of step k overlap the build of step k+1 when the rows are double-buffered."""
+        if self.uniform:
+            send = local_rows
+        else:
+            send = self.send
+            send[: local_rows.numel()].copy_(local_rows)
+        return self.dist.gather(send, self.recv, dst=self.dst, group=self.group, async_op=True)
+
     def __call__(self, local_rows):
         """Returns on dst the list of per-rank row tensors (views, valid until the next call)."""
         if self.uniform:
