@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — genomic sites/s of the 2-population FST window scan on MI355X (BASELINE.json metric).
 
-One step = one pass of the hot path over the columns resident in this rank's HBM: build the range
-tree (the streaming pass over a,b: 16 B/site) + answer every window (W=50000, S=10000 sites) +, for
-N>1, gather the window rows to rank 0 over RCCL.  Inputs are synthetic (BASELINE.md definition) and
-already in HBM when the timed region starts.
+Workload (BASELINE config 4 / north_star's target): ONE synthetic genome of --sites sites (default
+10^9) in --chroms chromosomes (default 40), window 50000 sites / step 10000 sites, columns resident
+in HBM when the timed region starts.  One step = one pass of the hot path over the whole genome:
+build the range tree (the streaming pass over a,b: 16 B/site) + answer every window.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Scaling is WEAK: every rank holds --sites sites (default 10^9 = 20 GB of columns) in --chroms
-chromosomes; the job is N x that.  value = all sites of all ranks / max-over-ranks time.
-Prints ONE JSON line on rank 0.
+N > 1 (one process per GPU): the window table is built once (identical on every rank) and cut by
+pgt_plan_shards into N contiguous blocks; rank r materialises ONLY its own site range [site_lo,
+site_hi) of the genome (counter-based generator keyed on the global site index, halo <= one window)
+and reduces its block.  Rows reach rank 0 either by peer stores over xGMI into rank 0's row buffer
+(no per-step collective; default when every rank can map it) or by an asynchronous double-buffered
+RCCL gather.  STRONG scaling: total work is fixed at --sites; value = --sites x steps / max-over-ranks
+time.  After the timed region rank 0 rebuilds the whole genome, runs the single-GPU scan and demands
+the assembled multi-GPU table to be bitwise equal ("rows_check"); the table's SHA-256 ("rows_sha256")
+is the same for every N.  --scaling weak instead gives every rank --sites sites (genome = N x --sites).
+
+The default N=1 run also times BASELINE configs 2, 3 and 5 in their one-GPU form at 10^8 sites
+("extra"; --headline-only skips them, e.g. under rocprofv3 --stats) and the reference CPU path on a
+bounded sample ("cpu_baseline").  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -30,37 +41,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import popgenomicstools_amd as pgt  # noqa: E402
-from popgenomicstools_amd._lib import FST_ROW_DTYPE, PGT_STAT_FST  # noqa: E402
-from popgenomicstools_amd.distributed import RowGatherer  # noqa: E402
-from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device  # noqa: E402
+from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_STAT_DXY, PGT_STAT_FST,  # noqa: E402
+                                       PGT_STAT_HET, WIN_DTYPE)
+from popgenomicstools_amd.distributed import RowExchange  # noqa: E402
+from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
+from synth_genome import SynthGenome  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
 BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
+SEED = 12345
 
 
-def synth_columns(n, n_chr, seed, dev):
-    """BASELINE.md synthetic table on the device: pos = running sum of U{1..59} gaps per chromosome,
-    b ~ U(0,.3), a = b*U(-.1,.6), both rounded to 6 decimals.  Generated per chromosome to bound
-    temporaries.  torch is plumbing here (device RNG), not the product."""
-    gen = torch.Generator(device=dev).manual_seed(seed)
-    a = torch.empty(n, dtype=torch.float64, device=dev)
-    b = torch.empty(n, dtype=torch.float64, device=dev)
-    pos = torch.empty(n, dtype=torch.int32, device=dev)
-    base = n // n_chr
-    lens = [base + (1 if c < n - base * n_chr else 0) for c in range(n_chr)]
-    o = 0
-    for L in lens:
-        bb = torch.round(torch.rand(L, generator=gen, device=dev, dtype=torch.float64) * 0.3e6) / 1e6
-        u = torch.rand(L, generator=gen, device=dev, dtype=torch.float64) * 0.7 - 0.1
-        a[o:o + L] = torch.round(bb * u * 1e6) / 1e6
-        b[o:o + L] = bb
-        pos[o:o + L] = torch.randint(1, 60, (L,), generator=gen, device=dev, dtype=torch.int32).cumsum(0, dtype=torch.int32)
-        o += L
-        del bb, u
-    return pos, a, b, np.array(lens, dtype=np.uint64)
-
-
-def cpu_baseline(pos, a, b, run_len, W, S, n_sample):
+def cpu_baseline(pos, a, b, genome, W, S, n_sample):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload:
     the first n_sample sites written as the tool's text input, then the UNMODIFIED reference binary
     (oracle/_ref/fstWindow, kind "reference") — or, if that binary did not travel, our restatement
@@ -71,7 +63,7 @@ def cpu_baseline(pos, a, b, run_len, W, S, n_sample):
     n_sample = int(min(n_sample, a.numel()))
     hp = pos[:n_sample].cpu().numpy().view(np.uint32)
     ha, hb = a[:n_sample].cpu().numpy(), b[:n_sample].cpu().numpy()
-    chr_ids = np.repeat(np.arange(run_len.size, dtype=np.uint32), run_len.astype(np.int64))[:n_sample]
+    chr_ids = genome.chr_ids_np(0, n_sample)
     tmpdir = tempfile.mkdtemp(prefix="pgt_bench_")
     path = os.path.join(tmpdir, "sample.fst.txt")
     orc.write_fst_text(path, chr_ids, hp, ha, hb)
@@ -93,17 +85,63 @@ def cpu_baseline(pos, a, b, run_len, W, S, n_sample):
                       f"the reference is single-threaded"}
 
 
-def measured_traffic(n_sites):
-    """HBM bytes per build launch from the PMC pass committed under profiles/ (collected separately:
-    rocprofv3 --pmc cannot run inside this process).  None when no such file exists for this size."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            t = json.load(open(p))
-            return t.get(str(int(n_sites)))
-        except Exception:
-            return None
-    return None
+def timed_config(ctx, call, alg_bytes, reps=15):
+    """One BASELINE config in its one-GPU form: median whole-step time from events on the launch stream
+    (= torch's current stream) and the build kernel's own time from the library's HIP events."""
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
+        call()
+        e1.record()
+    torch.cuda.synchronize()
+    step_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+    ctx.set_profiling(True)
+    bm = []
+    for _ in range(reps):
+        call()
+        bm.append(ctx.last_kernel_ms()[0])
+    ctx.set_profiling(False)
+    build_ms = float(np.median(bm))
+    return {"ms_per_step": step_ms, "build_kernel_ms": build_ms, "algorithmic_bytes": alg_bytes,
+            "roofline_frac": alg_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def extra_configs(ctx, dev, W, S, tree_pool):
+    """BASELINE configs 2, 3, 5 (one-GPU forms) at 10^8 sites in 20 chromosomes, same generator."""
+    n8 = 100_000_000
+    g8 = SynthGenome(SEED, n8, 20)
+    win_h = pgt.build_windows_sites(g8.run_len, W, S)
+    win = windows_to_device(win_h, dev)
+    nw = win_h.size
+    ctx.set_max_window(W)
+    out = {}
+    pos, a, b = g8.fst_columns_t(0, n8, dev)
+    rows = torch.empty(28 * nw * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    r = timed_config(ctx, lambda: ctx.fst_reduce_dev(pos, a, b, win, out=rows, tree=tree_pool), 16.0 * n8)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["fst_1e8"] = dict(r, config="BASELINE configs[1]: fstWindow 2 pops x 1e8 sites, 1 GPU", kernel="fst_build_kernel")
+    # config 3: dxyWindow + hetWindow of two genotype columns, one shared position column and window table
+    p1, p2, n1, n2 = g8.dxy_columns_t(0, n8, dev)
+    g1, g2 = g8.genotype_t(0, 0, n8, dev), g8.genotype_t(1, 0, n8, dev)
+    r = timed_config(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree_pool), 26.0 * n8)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["dxy_het_fused_1e8"] = dict(r, config="BASELINE configs[2]: dxyWindow + hetWindow x2, shared SoA, 1e8 sites, 1 GPU",
+                                    kernel="dxy_het_build_kernel")
+    del p1, p2, n1, n2, g1, g2
+    # config 5, one-GPU form: 28 population pairs batched over one table (grid.y = pair)
+    al, bl = [a], [b]
+    for p in range(1, 28):
+        pa, pb = g8.pair_columns_t(p, 0, n8, dev)
+        al.append(pa)
+        bl.append(pb)
+    r = timed_config(ctx, lambda: ctx.fst_reduce_pairs_dev(pos, al, bl, win, out=rows, tree=tree_pool), 448.0 * n8, reps=6)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["pairs28_1e8"] = dict(r, config="BASELINE configs[4], one-GPU form: fstWindow 28 pop-pairs x 1e8 sites batched",
+                              kernel="fst_build_kernel (grid.y = 28)")
+    return out
 
 
 def main():
@@ -111,16 +149,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=float, default=1e9, help="sites per GPU (weak scaling)")
-    ap.add_argument("--chroms", type=int, default=40, help="chromosomes per GPU")
+    ap.add_argument("--sites", type=float, default=1e9, help="sites of the genome (strong scaling) or per GPU (--scaling weak)")
+    ap.add_argument("--chroms", type=int, default=40, help="chromosomes of the genome (per GPU with --scaling weak)")
     ap.add_argument("--winsize", type=int, default=50_000)
     ap.add_argument("--stepsize", type=int, default=10_000)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--exchange", choices=["auto", "peer", "gather"], default="auto",
+                    help="how rows reach rank 0 when N > 1 (auto = peer stores if every rank can map the buffer, else gather)")
     ap.add_argument("--cpu-sites", type=float, default=5e7,
                     help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--extra", action="store_true",
-                    help="also time the 10^8-site configuration (BASELINE configs[1]) on the same buffers; off by "
-                         "default so that a rocprofv3 --stats average of the default command covers one size only")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,68 +183,107 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n, W, S = int(args.sites), args.winsize, args.stepsize
-    pos, a, b, run_len = synth_columns(n, args.chroms, 12345 + rank, dev)
-    win = pgt.build_windows_sites(run_len, W, S)  # host, O(#windows)
-    win_d = windows_to_device(win, dev)
+    W, S = args.winsize, args.stepsize
+    mult = world if args.scaling == "weak" else 1
+    n_total = int(args.sites) * mult
+    genome = SynthGenome(SEED, n_total, args.chroms * mult)
+    win = pgt.build_windows_sites(genome.run_len, W, S)  # host, O(#windows), identical on every rank
+    shards = pgt.plan_shards(win, world)
+    sh = shards[rank]
+    site_lo, site_hi = int(sh["site_lo"]), int(sh["site_hi"])
+    local = np.array(win[int(sh["win_begin"]): int(sh["win_end"])], dtype=WIN_DTYPE, copy=True)
+    local["lo"] -= site_lo
+    local["hi"] -= site_lo
+    n = site_hi - site_lo  # sites resident on this GPU (own block + halo)
+    pos, a, b = genome.fst_columns_t(site_lo, site_hi, dev)
+    win_d = windows_to_device(local, dev)
     ctx = pgt.Context(dev_index)
     ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
-    tree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
-    out = torch.empty(win.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    counts = [win.size] * world  # every rank has the same geometry
-    gather = RowGatherer(counts, FST_ROW_DTYPE.itemsize, coll_dev, dst=0) if world > 1 else None
-
-    # Opt-in (PGT_BENCH_ASYNC_GATHER=1, never set by the driver): rows are double-buffered and the
-    # gather of step k is only waited for before step k+2 reuses its buffer, so it overlaps the build
-    # of step k+1.  Default: the gather completes inside the step that produced the rows.
-    async_gather = gather is not None and os.environ.get("PGT_BENCH_ASYNC_GATHER") == "1"
-    outs = [out, torch.empty_like(out)] if async_gather else [out]
-    pending = [None, None]
-    counter = [0]
+    tree_bytes = max(ctx.tree_bytes(PGT_STAT_FST, n), 28 * ctx.tree_bytes(PGT_STAT_FST, 100_000_000),
+                     ctx.tree_bytes(PGT_STAT_DXY, 100_000_000) + 2 * ctx.tree_bytes(PGT_STAT_HET, 100_000_000)) \
+        if (world == 1 and not args.headline_only) else ctx.tree_bytes(PGT_STAT_FST, n)
+    tree = torch.empty(tree_bytes, dtype=torch.uint8, device=dev)
+    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64)
+    ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=args.exchange, coll_device=coll_dev)
 
     def step():
-        k = counter[0] & 1 if async_gather else 0
-        counter[0] += 1
-        if pending[k] is not None:
-            pending[k].wait()  # the gather that last read outs[k] must be done before it is overwritten
-            pending[k] = None
-        ctx.fst_reduce_dev(pos, a, b, win_d, out=outs[k], tree=tree)
-        if gather is None:
-            return outs[k]
-        rows = outs[k] if coll_dev is dev else outs[k].cpu()
-        if async_gather:
-            pending[k] = (gather.start(rows), rows)[0]
-            return None
-        return gather(rows)  # one RCCL gather of 40 B/window to rank 0
+        out = ex.begin()
+        ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
+        ex.end()
 
     def fence():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-        torch.cuda.synchronize()
+        ex.flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed_region()
+    table = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
+
+    # --- N > 1: the assembled table must be the single-GPU table, bit for bit ------------------
+    rows_check, sha, rows = None, None, None
+    single = {}
+
+    def single_gpu_table():
+        """rank 0: the whole genome on this one GPU through the same entry point (outside any timed region)."""
+        if "t" not in single:
+            fp, fa, fb = genome.fst_columns_t(0, n_total, dev)
+            ftree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n_total), dtype=torch.uint8, device=dev)
+            fout, _ = ctx.fst_reduce_dev(fp, fa, fb, windows_to_device(win, dev), tree=ftree)
+            single["t"] = fout.cpu().numpy().tobytes()
+        return single["t"]
+
+    can_verify = world > 1 and not args.no_verify and (args.scaling == "strong" or n_total <= 2_000_000_000)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        verdict = torch.zeros(1, dtype=torch.int32, device=coll_dev)
+        if rank == 0 and can_verify:
+            verdict[0] = 0 if single_gpu_table() == table.tobytes() else 1
+        dist.broadcast(verdict, src=0)
+        bad = int(verdict.item()) != 0
+        if bad and ex.mode == "peer":
+            # peer stores did not deliver the right table on this machine: measure the gather transport instead
+            if rank == 0:
+                print("bench.py: peer-store table differs from the single-GPU table; re-running with the RCCL gather",
+                      file=sys.stderr, flush=True)
+            ex.close()
+            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode="gather", coll_device=coll_dev)
+            dt = timed_region()
+            table = ex.finish()
+            if rank == 0:
+                verdict[0] = 0 if single_gpu_table() == table.tobytes() else 1
+            dist.broadcast(verdict, src=0)
+            bad = int(verdict.item()) != 0
+        if bad:
+            raise SystemExit("bench.py: the multi-GPU table differs from the single-GPU table of the same genome")
+        if rank == 0:
+            rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
+                          ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
+    if rank == 0:
+        sha = hashlib.sha256(table.tobytes()).hexdigest()
+        rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)
+        assert rows.size == win.size
 
     # --- roofline of the dominant kernel: HIP events on the launch stream, around the build pass only
+    scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
     ctx.set_profiling(True)
     build_ms, query_ms = [], []
     for _ in range(max(5, min(args.steps, 20))):
-        ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
+        ctx.fst_reduce_dev(pos, a, b, win_d, out=scratch, tree=tree)
         bm, qm = ctx.last_kernel_ms()
         build_ms.append(bm)
         query_ms.append(qm)
@@ -211,77 +291,61 @@ def main():
     build_avg = float(np.mean(build_ms))
     achieved = BYTES_PER_SITE * n / (build_avg * 1e-3) / 1e9  # GB/s
 
-    # --- the 10^8-site configuration (BASELINE configs[1]) on the same buffers, for the record
-    extra = {}
-    if args.extra and rank == 0 and n > 100_000_000:
-        n8 = 100_000_000
-        rl8 = np.full(20, n8 // 20, dtype=np.uint64)
-        win8 = windows_to_device(pgt.build_windows_sites(rl8, W, S), dev)
-        out8 = torch.empty(win8.numel() // 32 * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        for _ in range(3):
-            ctx.fst_reduce_dev(pos[:n8], a[:n8], b[:n8], win8, out=out8, tree=tree)
-        torch.cuda.synchronize()
-        # per-step time from events on the launch stream (= torch's current stream); median of 50,
-        # so that a one-off stall inside the loop does not pass for a per-step cost
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-        for e0, e1 in ev:
-            e0.record()
-            ctx.fst_reduce_dev(pos[:n8], a[:n8], b[:n8], win8, out=out8, tree=tree)
-            e1.record()
-        torch.cuda.synchronize()
-        d8 = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e-3
-        ctx.set_profiling(True)
-        b8 = []
-        for _ in range(10):
-            ctx.fst_reduce_dev(pos[:n8], a[:n8], b[:n8], win8, out=out8, tree=tree)
-            b8.append(ctx.last_kernel_ms()[0])
-        ctx.set_profiling(False)
-        extra["sites_1e8"] = {"value": n8 / d8, "ms_per_step": d8 * 1e3, "build_kernel_ms": float(np.mean(b8)),
-                              "roofline_frac": BYTES_PER_SITE * n8 / (float(np.mean(b8)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-
     # --- sanity: a sample of windows against float64 sums taken by torch (independent path)
-    rows = rows_from_device(out, FST_ROW_DTYPE)
-    for i in np.linspace(0, win.size - 1, 7).astype(int):
-        lo, hi = int(win["lo"][i]), int(win["hi"][i])
-        ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())
-        assert abs(rows["fst"][i] - ref) <= 1e-9 * abs(ref) + 1e-12, (i, rows["fst"][i], ref)
+    if rank == 0:
+        mine = np.arange(int(sh["win_begin"]), int(sh["win_end"]))
+        for i in mine[np.linspace(0, mine.size - 1, 7).astype(int)]:
+            lo, hi = int(win["lo"][i]) - site_lo, int(win["hi"][i]) - site_lo
+            ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())
+            assert abs(rows["fst"][i] - ref) <= 1e-9 * abs(ref) + 1e-12, (i, rows["fst"][i], ref)
+            assert rows["n"][i] == hi - lo and rows["start"][i] == (int(pos[lo]) & 0xFFFFFFFF)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(pos, a, b, run_len, W, S, args.cpu_sites)
+    extra, cpu = {}, None
+    if rank == 0 and world == 1:
+        if not args.headline_only:
+            extra = extra_configs(ctx, dev, W, S, tree)
+            ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
+        if not args.no_cpu:
+            cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites)
 
     if rank == 0:
-        total_sites = float(n) * world
+        per_gpu = [int(s["site_hi"] - s["site_lo"]) for s in shards]
         line = {
             "metric": "genomic sites/sec for 2-pop FST window scan",
-            "value": total_sites * args.steps / dt,
+            "value": float(n_total) * args.steps / dt,
             "unit": "sites/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"fstWindow 2 pops x {n:.0e} sites per GPU in {args.chroms} chromosomes, "
-                                   f"window {W} sites / step {S} sites, {win.size} windows per GPU, columns resident in HBM"
-                                   + (", rows gathered to rank 0 over RCCL" if world > 1 else ""),
-                       "baseline_config": "the 10^9-site two-population FST window scan north_star's target is quoted on "
-                                          "(it fits one GPU: 20 GB); BASELINE configs[1] (10^8 sites) is measured with --extra",
-                       "sites_per_gpu": n, "winsize": W, "stepsize": S, "windows_per_gpu": int(win.size),
-                       "parallelism": (f"site-range shards x{world}" + (", async gather" if async_gather else "")
-                                       + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
+            "config": {"workload": f"fstWindow 2 pops x {n_total:.0e} sites total in {genome.run_len.size} chromosomes"
+                                   + (f" sharded x{world} by window blocks (pgt_plan_shards)" if world > 1 else "")
+                                   + f", window {W} sites / step {S} sites, {win.size} windows, columns resident in HBM"
+                                   + (f", rows to rank 0 by {'peer stores over xGMI' if ex.mode == 'peer' else 'async RCCL gather'}"
+                                      if world > 1 else ""),
+                       "baseline_config": "BASELINE configs[3] (10^9-site fstWindow scan sharded over the GPUs; at N=1 the same genome "
+                                          "on one GPU: the size north_star's roofline target is quoted on); configs[1], [2], [4] in `extra`",
+                       "sites_total": n_total, "sites_resident_per_gpu": per_gpu, "winsize": W, "stepsize": S,
+                       "windows": int(win.size), "seed": SEED, "row_exchange": ex.mode,
+                       "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
                                       if world > 1 else "single GPU"},
+            "rows_sha256": sha,
+            "rows_check": rows_check,
             "roofline": {"bound": "hbm", "kernel": "fst_build_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_source": "profiles/r02/pmc_counters.csv (separate rocprofv3 --pmc passes; not measured by this run)",
                          "kernel_ms": build_avg, "query_kernel_ms": float(np.mean(query_ms)),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SITE * n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SITE * n, "sites_per_launch": n},
             "cpu_baseline": cpu,
             "extra": extra,
         }
         print(json.dumps(line), flush=True)
+    ex.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PGT_ABI_VERSION 1
+#define PGT_ABI_VERSION 2
 
 enum {
     PGT_OK = 0,
@@ -212,13 +212,35 @@ int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms);
 /* ---- multi-GPU sharding plan (host) ----------------------------------------------------- */
 /* Split a window table into n_ranks contiguous blocks balanced by reduced sites.  Rank r owns
  * windows [win_begin, win_end) and needs the site columns [site_lo, site_hi); site_lo is
- * rounded down to a multiple of 65536 so that every rank's range tree has the same node
- * boundaries as the single-GPU tree (results are then bitwise independent of n_ranks). */
+ * rounded down to a multiple of max(65536, the largest power of two <= the longest window), so
+ * that every tree node a query can touch (nodes are powers of two of sites for every statistic)
+ * has the same boundaries as in the single-GPU tree: results are bitwise independent of n_ranks. */
 typedef struct {
     uint64_t win_begin, win_end;
     uint64_t site_lo, site_hi;
 } pgt_shard;
 int pgt_plan_shards(const pgt_win *win, uint64_t n_win, uint32_t n_ranks, pgt_shard *out);
+
+/* ---- multi-GPU row exchange without a per-step collective ----------------- */
+/* The reference prints each window's row as soon as calcWindow has reduced it (fstWindow.cpp:88); in
+ * the sharded form rank 0 prints, so every rank's rows must reach rank 0.  Instead of a gather per
+ * scan, rank 0 creates ONE row buffer for the whole window table and exports it; every other rank
+ * (one process per GPU) opens it and passes `base + its first window * row size` as the `out`
+ * pointer of its *_dev call: the query kernel's row stores then travel over xGMI straight into rank
+ * 0's HBM.  After every rank has synchronised its stream (plus one barrier of the caller's process
+ * group) rank 0 holds the assembled table.  Rows of different ranks should start on 256-byte
+ * boundaries of the buffer (pad between blocks) so that no cache line is written by two GPUs.
+ *   create  hipMalloc on ctx's device + hipIpcGetMemHandle; the handle is 64 plain bytes that the
+ *           caller ships to the other processes (e.g. torch.distributed.broadcast_object_list)
+ *   open    hipIpcOpenMemHandle on ctx's device (peer mapping); fails in the creating process
+ *   close   owner != 0: hipFree;  owner == 0: hipIpcCloseMemHandle
+ *   read    rank 0: device -> host copy of the assembled rows, ordered after `stream` */
+#define PGT_IPC_HANDLE_BYTES 64
+typedef struct { unsigned char opaque[PGT_IPC_HANDLE_BYTES]; } pgt_ipc_handle;
+int pgt_rowbuf_create(pgt_ctx *ctx, size_t bytes, void **dev_ptr, pgt_ipc_handle *handle);
+int pgt_rowbuf_open(pgt_ctx *ctx, const pgt_ipc_handle *handle, void **dev_ptr);
+int pgt_rowbuf_close(pgt_ctx *ctx, void *dev_ptr, int owner);
+int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

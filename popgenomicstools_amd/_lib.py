@@ -44,6 +44,7 @@ SYMBOLS = [
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
+    "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
 ]
 
 
@@ -57,13 +58,13 @@ _lib = None
 
 
 def load() -> C.CDLL:
-    """Load libpgtwin.so, building it first if the sources are newer.  Raises if impossible."""
+    """Load libpgtwin.so; build.build_lib() rebuilds it first when a source, a header or the compile
+    flags changed since it was built (mtime / flag-stamp check, cheap).  Raises if impossible."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build
-        build.build_lib()
+    from . import build
+    build.build_lib()
     # One HIP runtime per process: torch ships its own libamdhip64.so.7 and /opt/rocm has another
     # with the same SONAME; whichever loads first serves both.  If torch loads second it finds no
     # device through the other copy, so let torch's copy load first whenever torch is installed
@@ -103,6 +104,10 @@ def load() -> C.CDLL:
     lib.pgt_set_profiling.argtypes = [vp, i32]
     lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pgt_plan_shards.argtypes = [vp, u64, u32, vp]
+    lib.pgt_rowbuf_create.argtypes = [vp, sz, C.POINTER(vp), vp]
+    lib.pgt_rowbuf_open.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.pgt_rowbuf_close.argtypes = [vp, vp, i32]
+    lib.pgt_rowbuf_read.argtypes = [vp, vp, vp, sz, vp]
     for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
         getattr(lib, name)
     _lib = lib

@@ -17,6 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libpgtwin.so")
+FLAGS = os.path.join(PKG, "libpgtwin.flags")
 
 LIB_SOURCES = ["pgt_kernels.hip", "pgt_af_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
 HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow", "ihsWindow", "xpehhWindow"]
@@ -43,13 +44,51 @@ def _run(cmd: list[str]) -> None:
         raise RuntimeError(f"build step failed: {cmd[0]} (exit {r.returncode})")
 
 
+def _stamp(flags: list[str], deps: list[str]) -> str:
+    """Compile flags + content hash of every source and header: what the library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read() + b"\0")
+    return " ".join(flags) + "\n" + h.hexdigest() + "\n"
+
+
 def build_lib(force: bool = False) -> str:
+    """(Re)build libpgtwin.so when the sources, headers or compile flags differ from the ones it was
+    built from (content hash + flags recorded beside it in libpgtwin.flags; independent of mtimes,
+    which a snapshot copy to the GPU box does not preserve).  Concurrent callers (the ranks of one
+    job) are serialised by a file lock and the library is replaced atomically.  Without hipcc (a box
+    that only received a prebuilt library) an existing library is used as it is."""
+    import fcntl
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
     deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(CSRC, "pgt_device.h"), os.path.join(ROOT, "include", "pgtwin.h")]
-    if force or _newer(LIB, deps):
-        extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPGT_TUNING_BUILD for tools/tune_build.py
-        _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + extra + srcs)
+    extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPGT_TUNING_BUILD for tools/tune_build.py
+    if "-DPGT_TUNING_BUILD" in extra:  # rejected kernel variants, kept outside the product tree
+        deps.append(os.path.join(ROOT, "tools", "pgt_build_experiments.inc"))
+        extra = extra + ["-I" + os.path.join(ROOT, "tools")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + extra
+    stamp = _stamp(flags, deps)
+
+    def stale() -> bool:
+        try:
+            return not os.path.exists(LIB) or open(FLAGS).read() != stamp
+        except OSError:
+            return True
+
+    if not force and not stale():
+        return LIB
+    have_hipcc = bool(shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))
+    if not force and os.path.exists(LIB) and not have_hipcc:
+        return LIB
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or stale():  # another rank may have built it while we waited
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            _run([_hipcc()] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", tmp] + srcs)
+            os.replace(tmp, LIB)
+            with open(FLAGS, "w") as f:
+                f.write(stamp)
     return LIB
 
 

@@ -87,10 +87,26 @@ EvSet events_for(pgt_ctx *ctx) {
     return e;
 }
 
-int use_device(pgt_ctx *ctx) {
-    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
-    return hip_check(ctx, hipSetDevice(ctx->device), "hipSetDevice");
-}
+// Every entry point runs on ctx's device and leaves the CALLER's current device as it found it (a
+// torch caller whose current device differs must not have it switched under its feet).
+struct DeviceScope {
+    int saved = -1;
+    bool switched = false;
+    int enter(pgt_ctx *ctx) {
+        if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        if (saved == ctx->device) return PGT_OK;
+        if (int rc = hip_check(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return rc;
+        switched = true;
+        return PGT_OK;
+    }
+    ~DeviceScope() {
+        if (switched && saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+#define PGT_USE_DEVICE(ctx)  \
+    DeviceScope device_scope; \
+    if (int rc_ = device_scope.enter(ctx)) return rc_
 
 }  // namespace
 
@@ -124,10 +140,16 @@ pgt_ctx *pgt_open(int device) {
                          ", but libpgtwin carries gfx950 (MI355X) code objects only");
         return nullptr;
     }
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
     if ((e = hipSetDevice(device)) != hipSuccess) {
         set_global_error(std::string("pgt_open: hipSetDevice: ") + hipGetErrorString(e));
         return nullptr;
     }
+    struct Restore {  // the caller's current device is left as it was found
+        int dev, ctx_dev;
+        ~Restore() { if (dev >= 0 && dev != ctx_dev) (void)hipSetDevice(dev); }
+    } restore{caller_device, device};
     std::string init_err;
     if (init_kernels(&init_err) != PGT_OK || init_af_kernels(&init_err) != PGT_OK) {
         set_global_error("pgt_open: " + init_err);
@@ -187,7 +209,8 @@ int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms) {
 int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *a, const double *const *b,
                              uint32_t n_pairs, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
                              void *tree, size_t tree_bytes, void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0) return PGT_OK;  // a shard without windows (more ranks than windows)
     if (!a || !b || n_pairs == 0 || !tree || (n_win && (!win || !out || !pos)))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
     for (uint32_t p = 0; p < n_pairs; ++p)
@@ -208,7 +231,8 @@ int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const
 
 int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
                        uint64_t n_win, pgt_het_row *out, void *tree, size_t tree_bytes, void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0) return PGT_OK;
     if (!g || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
     if (!aligned16(g)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: genotype column must be 16-byte aligned");
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: at most 2^32-1 sites per call");
@@ -221,7 +245,8 @@ int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                        const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                        pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, size_t tree_bytes, void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0 && !tot) return PGT_OK;
     if (!p1 || !p2 || !n1 || !n2 || !tree || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
     if (!aligned16(p1) || !aligned16(p2) || (reinterpret_cast<uintptr_t>(n1) & 7u) || (reinterpret_cast<uintptr_t>(n2) & 7u))
@@ -238,7 +263,8 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
                            const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
                            const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
                            pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, size_t tree_bytes, void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0 && !tot) return PGT_OK;
     if (!p1 || !p2 || !n1 || !n2 || !g1 || !g2 || !tree || (n_win && (!win || !dxy_out || !het_out1 || !het_out2 || !pos)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: NULL argument");
     if (!aligned16(p1) || !aligned16(p2) || !aligned16(g1) || !aligned16(g2) ||
@@ -260,7 +286,8 @@ size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites) {
 int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
                           uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
                           size_t tree_bytes, void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0) return PGT_OK;
     if (!freq || !nsamp || !tree || (n_win && (!win || !out || !pos)))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: NULL argument");
     if (n_pops < 2 || n_pops > (uint32_t)kAfMaxPops) return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: 2 <= n_pops <= 8");
@@ -279,7 +306,8 @@ int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const
 int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
                            const pgt_win *win, uint64_t n_win, pgt_ext_row *out, void *tree, size_t tree_bytes,
                            void *stream) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
+    if (n == 0 && n_win == 0) return PGT_OK;
     if (!score || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
     if (mode < PGT_EXT_IHS || mode > PGT_EXT_XP_MIN) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: unknown mode");
     if (!aligned16(score)) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: score column must be 16-byte aligned");
@@ -291,11 +319,58 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
                       ctx->max_window);
 }
 
+/* ---------------- multi-GPU row exchange ---------------- */
+
+static_assert(sizeof(hipIpcMemHandle_t) == PGT_IPC_HANDLE_BYTES, "pgt_ipc_handle must hold a hipIpcMemHandle_t");
+
+int pgt_rowbuf_create(pgt_ctx *ctx, size_t bytes, void **dev_ptr, pgt_ipc_handle *handle) {
+    PGT_USE_DEVICE(ctx);
+    if (!dev_ptr || !handle) return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_create: NULL argument");
+    void *p = nullptr;
+    if (int rc = hip_check(ctx, hipMalloc(&p, bytes ? bytes : 256), "pgt_rowbuf_create: hipMalloc")) return rc;
+    hipIpcMemHandle_t h;
+    if (int rc = hip_check(ctx, hipIpcGetMemHandle(&h, p), "pgt_rowbuf_create: hipIpcGetMemHandle")) {
+        (void)hipFree(p);
+        return rc;
+    }
+    std::memcpy(handle->opaque, &h, sizeof h);
+    *dev_ptr = p;
+    return PGT_OK;
+}
+
+int pgt_rowbuf_open(pgt_ctx *ctx, const pgt_ipc_handle *handle, void **dev_ptr) {
+    PGT_USE_DEVICE(ctx);
+    if (!dev_ptr || !handle) return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_open: NULL argument");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle->opaque, sizeof h);
+    void *p = nullptr;
+    if (int rc = hip_check(ctx, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "pgt_rowbuf_open: hipIpcOpenMemHandle"))
+        return rc;
+    *dev_ptr = p;
+    return PGT_OK;
+}
+
+int pgt_rowbuf_close(pgt_ctx *ctx, void *dev_ptr, int owner) {
+    PGT_USE_DEVICE(ctx);
+    if (!dev_ptr) return PGT_OK;
+    return owner ? hip_check(ctx, hipFree(dev_ptr), "pgt_rowbuf_close: hipFree")
+                 : hip_check(ctx, hipIpcCloseMemHandle(dev_ptr), "pgt_rowbuf_close: hipIpcCloseMemHandle");
+}
+
+int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, void *stream) {
+    PGT_USE_DEVICE(ctx);
+    if (bytes == 0) return PGT_OK;
+    if (!host_dst || !dev_src) return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_read: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = hip_check(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s), "pgt_rowbuf_read: copy")) return rc;
+    return hip_check(ctx, hipStreamSynchronize(s), "pgt_rowbuf_read: synchronize");
+}
+
 /* ---------------- host-buffer entry points ---------------- */
 
 int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
                        const pgt_win *win, uint64_t n_win, pgt_ext_row *out) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
@@ -318,7 +393,7 @@ int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, u
 
 int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
                    const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
@@ -341,7 +416,7 @@ int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const dou
 
 int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
                    uint64_t n_win, pgt_het_row *out) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
@@ -364,7 +439,7 @@ int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t 
 int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                    const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                    pgt_dxy_row *out, pgt_dxy_total *tot) {
-    if (int rc = use_device(ctx)) return rc;
+    PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !p1 || !p2 || !n1 || !n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;

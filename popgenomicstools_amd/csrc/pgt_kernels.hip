@@ -731,14 +731,6 @@ inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     return PGT_EDEVICE;
 }
 
-// 64 KiB of dynamic LDS per workgroup for the node stage: declared once per kernel
-template <auto Kernel>  // one static per kernel (a type parameter would be shared by kernels of equal signature)
-void allow_stage_lds() {
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes);
-    (void)once;
-}
-
 inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
     // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
     // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
@@ -824,7 +816,6 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
             launched = launch_fst_experiment(s, cols, np, n, tl, tv);
 #endif
             if (!launched) {
-                allow_stage_lds<fst_build_kernel<>>();
                 hipLaunchKernelGGL((fst_build_kernel<>), dim3(build_grid(tl.count[1], kFstBuildBlocks), np), dim3(256),
                                    kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
             }
@@ -875,7 +866,6 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        allow_stage_lds<dxy_build_kernel>();
         hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1], kFstBuildBlocks)), dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n,
                            minind, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
@@ -932,7 +922,6 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         const uint64_t n_items = het_items(n);
         DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], n_items, tvd, {tvh0, tvh1}};
         const uint64_t tiles = td.count[1] > n_items ? td.count[1] : n_items;
-        allow_stage_lds<dxy_het_build_kernel>();
         hipLaunchKernelGGL(dxy_het_build_kernel, dim3(build_grid(tiles, kFstBuildBlocks), 3), dim3(256), kFstStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;

@@ -239,11 +239,13 @@ extern "C" int pgt_plan_shards(const pgt_win *win, uint64_t n_win, uint32_t n_ra
         total = std::max(total, win[i].hi);
         max_len = std::max(max_len, win[i].hi - win[i].lo);
     }
-    // Align shard starts to the largest tree node a window can contain (all node sizes are powers
-    // of two: 2^7,2^13,2^19,.. for f64 columns and 2^10,2^16,2^22,.. for int8), never below 2^16:
-    // every node a query touches then covers the same sites as in the single-GPU tree.
+    // Align shard starts to the largest power of two not above the longest window, never below 2^16.
+    // Every tree node is a power of two of sites (2^7,2^13,2^19,.. for f64 column pairs, 2^10,2^16,2^22,..
+    // for int8, 2^8,2^14,2^20,.. for the extreme-score column), and a query only touches nodes that fit
+    // inside its window, so each of them divides this alignment whatever the statistic: every node a
+    // query touches covers the same sites as in the single-GPU tree.
     uint64_t align = 1ull << 16;
-    for (int sh = 19; sh <= 40; sh += 3)
+    for (int sh = 17; sh <= 62; ++sh)
         if ((1ull << sh) <= max_len) align = 1ull << sh;
     uint64_t w = 0;
     for (uint32_t r = 0; r < n_ranks; ++r) {

@@ -1,22 +1,32 @@
-"""Multi-GPU plumbing: one process per GPU, windows sharded by site range, one final gather.
+"""Multi-GPU plumbing: one process per GPU, windows sharded by site range, rows assembled on one rank.
 
 Windows are independent given their [lo,hi), so the data path needs no
 collective: rank r holds the site columns [site_lo, site_hi) of its shard (neighbouring shards
-overlap by at most one window length; the halo is loaded twice, never exchanged), reduces its
-own block of the window table, and the fixed-size rows are gathered to rank 0 — over RCCL/xGMI
-when the process group's backend is "nccl", over gloo in the CPU tests.  The gather moves
-40 B per window (≈4 MB for 10^9 sites at S=10^4): it is latency-bound, not link-bound.
+overlap by at most one window length; the halo is loaded twice, never exchanged) and reduces its
+own block of the window table.  What has to travel is the fixed-size rows (40 B per fst window,
+≈4 MB for 10^9 sites at S=10^4) to the rank that prints them — latency-bound, not link-bound.
+Two transports (RowExchange):
+
+  peer    rank `dst` owns ONE row buffer for the whole table (pgt_rowbuf_create), every other rank
+          maps it (hipIpc, pgt_rowbuf_open) and hands its slice to the *_dev call as `out`: the
+          query kernel's row stores cross xGMI into dst's HBM, no collective per scan, one barrier
+          when the caller wants the table.
+  gather  torch.distributed.gather of the rows (backend "nccl" = RCCL over xGMI; gloo in the CPU
+          tests), asynchronous and double-buffered so that the gather of scan k overlaps scan k+1.
+
+`mode="auto"` takes peer when every rank could map the buffer and falls back to gather otherwise
+(decided collectively, so all ranks agree).
 """
 from __future__ import annotations
 
 import numpy as np
 
-from ._lib import WIN_DTYPE
+from ._lib import WIN_DTYPE, PgtError
 from .window_scan import plan_shards
 
 
 def shard_windows(win: np.ndarray, rank: int, world: int):
-    """-> (shard record, this rank's windows re-based to its local columns)."""
+    """-> (shard record, this rank's windows re-based to its local columns, all shard records)."""
     shards = plan_shards(win, world)
     s = shards[rank]
     local = np.array(win[int(s["win_begin"]): int(s["win_end"])], dtype=WIN_DTYPE, copy=True)
@@ -25,9 +35,18 @@ def shard_windows(win: np.ndarray, rank: int, world: int):
     return s, local, shards
 
 
+def _global_dst(dist, group, dst: int) -> int:
+    """`dst` is a rank of `group`; torch.distributed.gather / broadcast want the global rank."""
+    return dist.get_global_rank(group, dst) if group is not None else dst
+
+
+def _align(x: int, a: int = 256) -> int:
+    return (x + a - 1) // a * a
+
+
 class RowGatherer:
-    """gather_rows with its buffers allocated once (the bench's per-step path): when every rank has
-    the same number of windows the local row tensor is sent as it is, no staging copy."""
+    """gather_rows with its buffers allocated once (the per-scan path): when every rank has the same
+    number of rows the local row tensor is sent as it is, no staging copy.  `dst` is a rank of `group`."""
 
     def __init__(self, counts, row_bytes: int, device, dst: int = 0, group=None):
         import torch
@@ -37,43 +56,42 @@ class RowGatherer:
         self.row_bytes, self.dst, self.group = row_bytes, dst, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.width = max(self.counts) * row_bytes
-        self.uniform = len(set(self.counts)) == 1
+        self.gdst = _global_dst(dist, group, dst)
+        self.width = max(max(self.counts) * row_bytes, 1)
+        self.uniform = len(set(self.counts)) == 1 and self.counts[0] > 0
         self.send = None if self.uniform else torch.zeros(self.width, dtype=torch.uint8, device=device)
         self.recv = ([torch.empty(self.width, dtype=torch.uint8, device=device) for _ in range(self.world)]
                      if self.rank == dst else None)
 
+    def _staged(self, local_rows):
+        if self.uniform:
+            return local_rows
+        if local_rows is not None and local_rows.numel():
+            self.send[: local_rows.numel()].copy_(local_rows)
+        return self.send
+
     def start(self, local_rows):
         """Asynchronous form: issues the gather and returns its Work handle; the caller must keep
         `local_rows` untouched until handle.wait() (a stream-level wait) has been issued.  Lets the
-        gather of step k overlap the build of step k+1 when the rows are double-buffered."""
-        if self.uniform:
-            send = local_rows
-        else:
-            send = self.send
-            send[: local_rows.numel()].copy_(local_rows)
-        return self.dist.gather(send, self.recv, dst=self.dst, group=self.group, async_op=True)
+        gather of scan k overlap the build of scan k+1 when the rows are double-buffered."""
+        return self.dist.gather(self._staged(local_rows), self.recv, dst=self.gdst, group=self.group, async_op=True)
 
     def __call__(self, local_rows):
         """Returns on dst the list of per-rank row tensors (views, valid until the next call)."""
-        if self.uniform:
-            send = local_rows
-        else:
-            send = self.send
-            send[: local_rows.numel()].copy_(local_rows)
-        self.dist.gather(send, self.recv, dst=self.dst, group=self.group)
+        self.dist.gather(self._staged(local_rows), self.recv, dst=self.gdst, group=self.group)
+        return self.parts()
+
+    def parts(self):
         if self.rank != self.dst:
             return None
         return [self.recv[r][: self.counts[r] * self.row_bytes] for r in range(self.world)]
 
 
 def gather_rows(local_rows, counts, row_bytes: int, dst: int = 0, group=None):
-    """Gather per-rank packed row tensors (uint8, counts[r]*row_bytes bytes on rank r) to `dst`.
-
-    local_rows: torch uint8 tensor on the rank's device (CUDA for nccl/RCCL, CPU for gloo).
-    counts: windows per rank, known to every rank from the shard plan (no size exchange needed).
-    Returns on dst the concatenated uint8 tensor in window order; None elsewhere.
-    """
+    """Gather per-rank packed row tensors (uint8, counts[r]*row_bytes bytes on rank r) to `dst` (a rank
+    of `group`).  local_rows: torch uint8 tensor on the rank's device (CUDA for nccl/RCCL, CPU for gloo).
+    counts: rows per rank, known to every rank from the shard plan (no size exchange needed).
+    Returns on dst the concatenated uint8 tensor in window order; None elsewhere."""
     import torch
     import torch.distributed as dist
 
@@ -81,41 +99,187 @@ def gather_rows(local_rows, counts, row_bytes: int, dst: int = 0, group=None):
     rank = dist.get_rank(group)
     if world == 1:
         return local_rows
-    width = int(max(counts)) * row_bytes
-    send = torch.zeros(width, dtype=torch.uint8, device=local_rows.device)
-    send[: local_rows.numel()] = local_rows
-    recv = [torch.empty(width, dtype=torch.uint8, device=local_rows.device) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([recv[r][: int(counts[r]) * row_bytes] for r in range(world)])
+    parts = RowGatherer(counts, row_bytes, local_rows.device, dst=dst, group=group)(local_rows)
+    return torch.cat(parts) if rank == dst else None
 
 
-def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows, device, dst: int = 0, group=None):
+class RowExchange:
+    """Rows of every rank's window block -> rank `dst`, once per scan, for a fixed shard plan.
+
+        ex = RowExchange(ctx, counts, row_bytes, device)       # collective (every rank of the group)
+        for every scan:
+            out = ex.begin()                                   # where this scan's rows go (pass as out=)
+            ctx.fst_reduce_dev(..., out=out, ...)
+            ex.end()                                           # gather mode: starts the async gather
+        table = ex.finish()                                    # collective; uint8 numpy on dst, None elsewhere
+
+    counts[r] = rows rank r produces per scan (tables * windows of its shard).  With tables > 1
+    (population pairs) a rank's block is table-major over ITS windows; finish() re-interleaves to
+    table-major over ALL windows.  coll_device: where collective tensors live (the GPU for nccl,
+    CPU for gloo); defaults to `device`.
+    """
+
+    def __init__(self, ctx, counts, row_bytes: int, device, dst: int = 0, group=None, mode: str = "auto",
+                 tables: int = 1, coll_device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.ctx = torch, dist, ctx
+        self.counts = [int(c) for c in counts]
+        self.row_bytes, self.dst, self.group, self.tables = int(row_bytes), dst, group, int(tables)
+        self.device = device
+        self.coll_device = coll_device if coll_device is not None else device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.my_bytes = self.counts[self.rank] * self.row_bytes
+        self.offsets = [0] * self.world  # 256-byte aligned block starts: no cache line is written by two GPUs
+        for r in range(1, self.world):
+            self.offsets[r] = _align(self.offsets[r - 1] + self.counts[r - 1] * self.row_bytes)
+        self.total = _align(self.offsets[-1] + self.counts[-1] * self.row_bytes)
+        self.mode = "local" if self.world == 1 else mode
+        self.buf = None       # peer: the shared row buffer (owned on dst, mapped elsewhere)
+        self.peer_error = ""
+        if self.mode in ("auto", "peer"):
+            ok = self._setup_peer()
+            if not ok and self.mode == "peer":
+                raise PgtError(3, "RowExchange: peer mapping of the row buffer failed on some rank: " + self.peer_error)
+            self.mode = "peer" if ok else "gather"
+        if self.mode in ("gather", "local"):
+            n = max(self.my_bytes, 1)
+            depth = 2 if self.mode == "gather" else 1
+            self.outs = [torch.empty(n, dtype=torch.uint8, device=device)[: self.my_bytes] for _ in range(depth)]
+            self.pending = [None] * depth
+            self.k = 0
+            self.last = 0
+            self.gatherer = (RowGatherer(self.counts, self.row_bytes, self.coll_device, dst=dst, group=group)
+                             if self.mode == "gather" else None)
+
+    # ---- peer ------------------------------------------------------------------------------
+    def _setup_peer(self) -> bool:
+        dist, torch = self.dist, self.torch
+        gdst = _global_dst(dist, self.group, self.dst)
+        box = [None]
+        ok = 1
+        if self.rank == self.dst:
+            try:
+                self.buf, handle = self.ctx.rowbuf_create(self.total)
+                box[0] = handle
+            except PgtError as e:
+                self.peer_error, ok = str(e), 0
+        dist.broadcast_object_list(box, src=gdst, group=self.group)
+        if self.rank != self.dst:
+            if box[0] is None:
+                ok = 0
+            else:
+                try:
+                    self.buf = self.ctx.rowbuf_open(box[0], self.total)
+                except PgtError as e:
+                    self.peer_error, ok = str(e), 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self.my_out = self.buf.view(self.offsets[self.rank], self.my_bytes)
+            return True
+        self._close_peer()
+        return False
+
+    def _close_peer(self):
+        if self.buf is not None:
+            try:
+                self.ctx.rowbuf_close(self.buf, owner=self.rank == self.dst)
+            except PgtError:
+                pass
+            self.buf = None
+
+    # ---- per scan --------------------------------------------------------------------------
+    def begin(self):
+        if self.mode == "peer":
+            return self.my_out
+        if self.pending[self.k] is not None:  # the gather that last read this buffer must be done
+            self.pending[self.k].wait()
+            self.pending[self.k] = None
+        return self.outs[self.k]
+
+    def end(self):
+        if self.mode == "gather":
+            rows = self.outs[self.k]
+            if self.coll_device != self.device and self.coll_device.type == "cpu":
+                rows = rows.cpu()
+            self._host_rows = rows  # keep a staged CPU copy alive until the gather has read it
+            self.pending[self.k] = self.gatherer.start(rows)
+            self.last = self.k
+            self.k ^= 1
+        elif self.mode == "local":
+            self.last = 0
+
+    def flush(self):
+        """Every transfer issued so far is complete on this rank's side (not a barrier)."""
+        if self.mode == "gather":
+            for k in range(len(self.pending)):
+                if self.pending[k] is not None:
+                    self.pending[k].wait()
+                    self.pending[k] = None
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def finish(self):
+        """Collective: the table of the LAST scan, assembled on dst in window order (uint8 numpy)."""
+        torch, dist = self.torch, self.dist
+        self.flush()
+        if self.world > 1:
+            dist.barrier(group=self.group)  # peer: every rank's row stores have landed in dst's buffer
+        if self.rank != self.dst:
+            return None
+        if self.mode == "peer":
+            raw = self.ctx.rowbuf_read(self.buf, self.total)
+            parts = [raw[self.offsets[r]: self.offsets[r] + self.counts[r] * self.row_bytes] for r in range(self.world)]
+        elif self.mode == "gather":
+            parts = [p.cpu().numpy() for p in self.gatherer.parts()]
+        else:
+            parts = [self.outs[0].cpu().numpy()]
+        if self.tables == 1:
+            return np.concatenate(parts) if len(parts) > 1 else np.array(parts[0], copy=True)
+        blocks = [p.reshape(self.tables, -1) for p in parts]  # [tables][rows of rank r * row_bytes]
+        return np.concatenate(blocks, axis=1).reshape(-1)
+
+    def close(self):
+        if self.world > 1:
+            self.flush()
+            self.dist.barrier(group=self.group)  # nobody unmaps / frees while a peer may still write
+        self._close_peer()
+
+
+def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows, device, dst: int = 0, group=None,
+                 tables: int = 1, ctx=None, mode: str = "gather", coll_device=None):
     """The whole multi-GPU path for one input, to be called by every rank of the process group.
 
       win           the full window table (identical on every rank; built on the host in O(#windows))
       load_columns  callable(site_lo, site_hi) -> whatever reduce_rows needs for sites [site_lo, site_hi):
                     a rank only ever touches its own shard (plus a halo of at most one window)
-      reduce_rows   callable(columns, local_win) -> packed uint8 torch tensor of len(local_win) rows on
-                    `device` (e.g. lambda c, w: ctx.fst_reduce_dev(*c, windows_to_device(w, dev))[0])
-    Returns on `dst` the assembled rows as a numpy structured array in window order, None elsewhere.
-    One collective: the gather of the fixed-size rows (RCCL when the backend is nccl).
+      reduce_rows   callable(columns, local_win, out) -> None; writes tables * len(local_win) packed rows
+                    (table-major) into `out`, e.g. lambda c, w, out: ctx.fst_reduce_dev(*c, windows_to_device(w, dev), out=out)
+      tables        rows per window: 1, or the number of population pairs of fst_reduce_pairs_dev /
+                    fst_af_reduce_dev (BASELINE config 5)
+      mode          "gather" (one RCCL/gloo gather) or "peer"/"auto" (needs ctx: rows stored straight into
+                    dst's buffer over xGMI)
+    Returns on `dst` (a rank of `group`) the assembled rows as a numpy structured array, table-major over
+    all windows; None elsewhere.  A rank whose shard holds no window (more ranks than windows) loads
+    nothing, reduces nothing and still takes part in the exchange.
     """
-    import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     shard, local_win, shards = shard_windows(win, rank, world)
-    columns = load_columns(int(shard["site_lo"]), int(shard["site_hi"]))
-    rows = reduce_rows(columns, local_win)
-    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64)
-    if world == 1:
-        packed = rows
-    else:
-        parts = RowGatherer(counts, row_dtype.itemsize, device, dst=dst, group=group)(rows)
-        packed = torch.cat(parts) if rank == dst else None
+    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64) * int(tables)
+    ex = RowExchange(ctx, counts, row_dtype.itemsize, device, dst=dst, group=group, mode=mode, tables=tables,
+                     coll_device=coll_device)
+    out = ex.begin()
+    if local_win.size:
+        columns = load_columns(int(shard["site_lo"]), int(shard["site_hi"]))
+        reduce_rows(columns, local_win, out)
+    ex.end()
+    packed = ex.finish()
+    ex.close()
     if rank != dst:
         return None
-    return np.frombuffer(packed.cpu().numpy().tobytes(), dtype=row_dtype)
+    return np.frombuffer(packed.tobytes(), dtype=row_dtype)

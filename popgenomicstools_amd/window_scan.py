@@ -91,6 +91,26 @@ def plan_shards(win: np.ndarray, n_ranks: int) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
+# raw device memory handed out by the library (pgt_rowbuf_*): quacks like the uint8 tensors the
+# *_dev wrappers take (data_ptr / numel), so it can be passed as `out=`
+# ---------------------------------------------------------------------------------------------
+class RowBuffer:
+    def __init__(self, ptr: int, nbytes: int, owner=None):
+        self._ptr, self._nbytes, self._owner = int(ptr), int(nbytes), owner  # owner keeps the mapping alive
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def numel(self) -> int:
+        return self._nbytes
+
+    def view(self, offset: int, nbytes: int) -> "RowBuffer":
+        if offset < 0 or nbytes < 0 or offset + nbytes > self._nbytes:
+            raise PgtError(_lib.PGT_EARG, "RowBuffer.view outside the buffer")
+        return RowBuffer(self._ptr + offset, nbytes, self._owner or self)
+
+
+# ---------------------------------------------------------------------------------------------
 # context
 # ---------------------------------------------------------------------------------------------
 class Context:
@@ -188,9 +208,48 @@ class Context:
     @staticmethod
     def _dev(t, dtype, name):
         import torch
+        if isinstance(t, RowBuffer) and dtype == torch.uint8:
+            return t.data_ptr()
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
             raise PgtError(_lib.PGT_EARG, f"{name}: expected a contiguous CUDA tensor of {dtype}")
-        return t.data_ptr()
+        return t.data_ptr() if t.numel() else None  # an empty shard passes NULL columns (n == 0)
+
+    @staticmethod
+    def _same_len(name, n, *cols):
+        """The C ABI takes one n for all columns: a short column would be read out of bounds."""
+        for c in cols:
+            if c.numel() != n:
+                raise PgtError(_lib.PGT_EARG, f"{name}: column lengths differ ({c.numel()} vs {n})")
+
+    @staticmethod
+    def _room(name, buf, need_bytes):
+        """The C ABI gets no output capacity: an undersized buffer would be a silent device overrun."""
+        if buf.numel() < need_bytes:
+            raise PgtError(_lib.PGT_EARG, f"{name}: buffer holds {buf.numel()} bytes, {need_bytes} needed")
+
+    # ---- multi-GPU row buffer (pgt_rowbuf_*) ------------------------------------------------
+    def rowbuf_create(self, nbytes: int):
+        """-> (RowBuffer on this GPU, 64-byte IPC handle to ship to the other ranks)."""
+        ptr = C.c_void_p(0)
+        handle = (C.c_ubyte * 64)()
+        self._check(self._lib.pgt_rowbuf_create(self._ctx, int(nbytes), C.byref(ptr), handle))
+        return RowBuffer(ptr.value, nbytes), bytes(handle)
+
+    def rowbuf_open(self, handle: bytes, nbytes: int) -> RowBuffer:
+        ptr = C.c_void_p(0)
+        h = (C.c_ubyte * 64).from_buffer_copy(handle)
+        self._check(self._lib.pgt_rowbuf_open(self._ctx, h, C.byref(ptr)))
+        return RowBuffer(ptr.value, nbytes)
+
+    def rowbuf_close(self, buf: RowBuffer, owner: bool):
+        self._check(self._lib.pgt_rowbuf_close(self._ctx, C.c_void_p(buf.data_ptr()), int(owner)))
+
+    def rowbuf_read(self, buf: RowBuffer, nbytes: int | None = None, stream=None) -> np.ndarray:
+        nbytes = buf.numel() if nbytes is None else int(nbytes)
+        host = np.empty(nbytes, dtype=np.uint8)
+        self._check(self._lib.pgt_rowbuf_read(self._ctx, host.ctypes.data, C.c_void_p(buf.data_ptr()), nbytes,
+                                              self._stream(stream)))
+        return host
 
     def fst_reduce_dev(self, pos, a, b, win, out=None, tree=None, stream=None):
         """pos u32-as-int32 [n], a/b float64 [n], win uint8 [n_win*32] (WIN_DTYPE bytes) on the GPU.
@@ -203,6 +262,9 @@ class Context:
             tree = torch.empty(tb, dtype=torch.uint8, device=a.device)
         if out is None:
             out = torch.empty(n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=a.device)
+        self._same_len("fst_reduce_dev", n, pos, a, b)
+        self._room("fst_reduce_dev: out", out, n_win * FST_ROW_DTYPE.itemsize)
+        self._room("fst_reduce_dev: tree", tree, tb)
         self._check(self._lib.pgt_fst_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(a, torch.float64, "a"),
             self._dev(b, torch.float64, "b"), n, self._dev(win, torch.uint8, "win"), n_win,
@@ -220,6 +282,9 @@ class Context:
             tree = torch.empty(tb, dtype=torch.uint8, device=pos.device)
         if out is None:
             out = torch.empty(n_pairs * n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=pos.device)
+        self._same_len("fst_reduce_pairs_dev", n, pos, *a_list, *b_list)
+        self._room("fst_reduce_pairs_dev: out", out, n_pairs * n_win * FST_ROW_DTYPE.itemsize)
+        self._room("fst_reduce_pairs_dev: tree", tree, tb)
         pa = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "a") for t in a_list])
         pb = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "b") for t in b_list])
         self._check(self._lib.pgt_fst_reduce_pairs_dev(
@@ -236,6 +301,9 @@ class Context:
             tree = torch.empty(self.tree_bytes(PGT_STAT_HET, n), dtype=torch.uint8, device=g.device)
         if out is None:
             out = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=g.device)
+        self._same_len("het_reduce_dev", n, pos, g)
+        self._room("het_reduce_dev: out", out, n_win * HET_ROW_DTYPE.itemsize)
+        self._room("het_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_HET, n))
         self._check(self._lib.pgt_het_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(g, torch.int8, "g"), n,
             self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
@@ -252,6 +320,9 @@ class Context:
             out = torch.empty(n_win * DXY_ROW_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
         if tot is None:
             tot = torch.empty(DXY_TOTAL_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
+        self._same_len("dxy_reduce_dev", n, pos, p1, p2, n1, n2)
+        self._room("dxy_reduce_dev: out", out, n_win * DXY_ROW_DTYPE.itemsize)
+        self._room("dxy_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_DXY, n))
         self._check(self._lib.pgt_dxy_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
             self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
@@ -273,6 +344,8 @@ class Context:
         tot = torch.empty(DXY_TOTAL_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         h1 = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         h2 = torch.empty(n_win * HET_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self._same_len("dxy_het_reduce_dev", n, pos, p1, p2, n1, n2, g1, g2)
+        self._room("dxy_het_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_DXY, n) + 2 * self.tree_bytes(PGT_STAT_HET, n))
         self._check(self._lib.pgt_dxy_het_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
             self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
@@ -296,12 +369,34 @@ class Context:
             tree = torch.empty(tb, dtype=torch.uint8, device=pos.device)
         if out is None:
             out = torch.empty(n_pairs * n_win * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=pos.device)
+        self._same_len("fst_af_reduce_dev", n, pos, *freqs)
+        self._room("fst_af_reduce_dev: out", out, n_pairs * n_win * FST_ROW_DTYPE.itemsize)
+        self._room("fst_af_reduce_dev: tree", tree, tb)
         pf = (C.c_void_p * n_pops)(*[self._dev(t, torch.float64, "freq") for t in freqs])
         ns = (C.c_double * n_pops)(*[float(x) for x in nsamp])
         self._check(self._lib.pgt_fst_af_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), pf, ns, n_pops, n, self._dev(win, torch.uint8, "win"),
             n_win, self._dev(out, torch.uint8, "out"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
             self._stream(stream)))
+        return out, tree
+
+    def extreme_reduce_dev(self, pos, score, mode, cutoff, win, out=None, tree=None, stream=None):
+        """ihsWindow / xpehhWindow rows from a device-resident score column (mode: PGT_EXT_*)."""
+        import torch
+        n = score.numel()
+        n_win = win.numel() // WIN_DTYPE.itemsize
+        tb = self.tree_bytes(PGT_STAT_EXT, n)
+        if tree is None:
+            tree = torch.empty(tb, dtype=torch.uint8, device=score.device)
+        if out is None:
+            out = torch.empty(n_win * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=score.device)
+        self._same_len("extreme_reduce_dev", n, pos, score)
+        self._room("extreme_reduce_dev: out", out, n_win * EXT_ROW_DTYPE.itemsize)
+        self._room("extreme_reduce_dev: tree", tree, tb)
+        self._check(self._lib.pgt_extreme_reduce_dev(
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(score, torch.float64, "score"), n, int(mode),
+            float(cutoff), self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree
 
     def set_max_window(self, sites: int):

@@ -1,0 +1,114 @@
+"""Multi-rank worker with the REAL HIP kernels, for the one-GPU box: started by tests/test_gpu_parity.py as
+    python -m torch.distributed.run --nproc-per-node R tests/hip_rank_worker.py
+(gloo for the collectives, every rank on GPU 0 — the launcher runs before anything touches the GPU).
+Each rank materialises only its own site range of one counter-based synthetic genome, reduces its
+block of the window table through the C-ABI device entry points, and the rows travel to rank 0 through
+popgenomicstools_amd.distributed (both transports: the gather, and peer stores into rank 0's row
+buffer through hipIpc).  Rank 0 demands the bytes of the single-GPU call on the whole input.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import popgenomicstools_amd as pgt  # noqa: E402
+from popgenomicstools_amd._lib import EXT_ROW_DTYPE, FST_ROW_DTYPE, PGT_EXT_IHS  # noqa: E402
+from popgenomicstools_amd.distributed import sharded_scan  # noqa: E402
+from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device  # noqa: E402
+from synth_genome import SynthGenome  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev, cpu = torch.device("cuda", 0), torch.device("cpu")
+    ctx = pgt.Context(0)
+    n, W, S = 3_000_000, 50_000, 10_000
+    g = SynthGenome(4242, n, 5)
+    win = pgt.build_windows_sites(g.run_len, W, S)
+    ctx.set_max_window(W)
+
+    def whole(fn):  # rank 0: the single-GPU answer on the whole input
+        if rank != 0:
+            return None
+        return fn()
+
+    # ---- fstWindow, one pair ----------------------------------------------------------------
+    def fst_reduce(c, w, out):
+        ctx.fst_reduce_dev(*c, windows_to_device(w, dev), out=out)
+    ref = whole(lambda: rows_from_device(ctx.fst_reduce_dev(*g.fst_columns_t(0, n, dev), windows_to_device(win, dev))[0],
+                                         FST_ROW_DTYPE).tobytes())
+    for mode in ("gather", "peer", "auto"):
+        got = sharded_scan(win, FST_ROW_DTYPE, lambda lo, hi: g.fst_columns_t(lo, hi, dev), fst_reduce, dev,
+                           ctx=ctx, mode=mode, coll_device=cpu)
+        if rank == 0:
+            assert got.size == win.size and got.tobytes() == ref, f"fst {mode}"
+            print(f"HIP_RANKS_OK fst {mode}", flush=True)
+
+    # ---- BASELINE config 5: population pairs batched over one table (tables = pairs) ----------
+    n_pairs = 5
+
+    def pair_cols(lo, hi):
+        cols = [g.pair_columns_t(p, lo, hi, dev) for p in range(n_pairs)]
+        return g.pos_t(lo, hi, dev), [c[0] for c in cols], [c[1] for c in cols]
+
+    def pairs_reduce(c, w, out):
+        ctx.fst_reduce_pairs_dev(c[0], c[1], c[2], windows_to_device(w, dev), out=out)
+    ref = whole(lambda: rows_from_device(ctx.fst_reduce_pairs_dev(*pair_cols(0, n), windows_to_device(win, dev))[0],
+                                         FST_ROW_DTYPE).tobytes())
+    for mode in ("gather", "peer"):
+        got = sharded_scan(win, FST_ROW_DTYPE, pair_cols, pairs_reduce, dev, tables=n_pairs, ctx=ctx, mode=mode, coll_device=cpu)
+        if rank == 0:
+            assert got.size == n_pairs * win.size and got.tobytes() == ref, f"pairs {mode}"
+            print(f"HIP_RANKS_OK pairs {mode}", flush=True)
+
+    # ---- the same pairs from allele frequencies (pgt_fst_af_reduce_dev) -------------------------
+    n_pops, nsamp = 4, [10.0, 12.0, 9.0, 20.0]
+
+    def af_cols(lo, hi):
+        return g.pos_t(lo, hi, dev), [g.freq_t(k, lo, hi, dev) for k in range(n_pops)]
+
+    def af_reduce(c, w, out):
+        ctx.fst_af_reduce_dev(c[0], c[1], nsamp, windows_to_device(w, dev), out=out)
+    ref = whole(lambda: rows_from_device(ctx.fst_af_reduce_dev(*af_cols(0, n), nsamp, windows_to_device(win, dev))[0],
+                                         FST_ROW_DTYPE).tobytes())
+    got = sharded_scan(win, FST_ROW_DTYPE, af_cols, af_reduce, dev, tables=n_pops * (n_pops - 1) // 2, ctx=ctx,
+                       mode="peer", coll_device=cpu)
+    if rank == 0:
+        assert got.tobytes() == ref, "af"
+        print("HIP_RANKS_OK af peer", flush=True)
+
+    # ---- ihsWindow-style extreme scan with windows >= 2^20 sites (upper tree levels in play) -----
+    ctx.set_max_window(0)
+    g1 = SynthGenome(4243, n, 1)  # one chromosome of ~9e7 bp
+    hp = g1.fst_columns_np(0, n)[0]
+    ewin = pgt.build_windows_extreme(hp, g1.run_len, None, 40_000_000)  # ~1.3e6 sites per window
+
+    def ext_cols(lo, hi):
+        p, a, _ = g1.fst_columns_t(lo, hi, dev)
+        return p, (a * 40.0 - 2.0)
+
+    def ext_reduce(c, w, out):
+        # position/value refer to GLOBAL sites only through pos[] and score[], both local here: fine
+        ctx.extreme_reduce_dev(c[0], c[1], PGT_EXT_IHS, 2.0, windows_to_device(w, dev), out=out)
+    ref = whole(lambda: rows_from_device(ctx.extreme_reduce_dev(*ext_cols(0, n), PGT_EXT_IHS, 2.0, windows_to_device(ewin, dev))[0],
+                                         EXT_ROW_DTYPE).tobytes())
+    got = sharded_scan(ewin, EXT_ROW_DTYPE, ext_cols, ext_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu)
+    if rank == 0:
+        assert int((ewin["hi"] - ewin["lo"]).max()) >= 1 << 20
+        assert got.tobytes() == ref, "extreme"
+        print("HIP_RANKS_OK extreme peer", flush=True)
+
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -679,7 +679,7 @@ def test_sharded_scan_single_rank_rccl(pgt, ctx):
         def load(lo, hi):
             return (torch.from_numpy(pos[lo:hi].view(np.int32)).to(dev), torch.from_numpy(a[lo:hi]).to(dev),
                     torch.from_numpy(b[lo:hi]).to(dev))
-        rows = sharded_scan(win, FST_ROW_DTYPE, load, lambda c, w: ctx.fst_reduce_dev(*c, windows_to_device(w, dev))[0], dev)
+        rows = sharded_scan(win, FST_ROW_DTYPE, load, lambda c, w, out: ctx.fst_reduce_dev(*c, windows_to_device(w, dev), out=out), dev, ctx=ctx)
     finally:
         dist.destroy_process_group()
     assert rows.tobytes() == ctx.fst_reduce(pos, a, b, win).tobytes()
@@ -712,3 +712,224 @@ def test_pairs_sharded_equals_single_bitwise(pgt, ctx):
             s, local, _ = shard_windows(win, rank, world)
             parts.append(run(int(s["site_lo"]), int(s["site_hi"]), local))
         assert np.concatenate(parts, axis=1).tobytes() == single.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: the real multi-rank product path on the one-GPU box, and the config / branch holes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_multi_rank_hip_path_two_ranks_one_gpu():
+    """Two processes (fresh children of a torch.distributed.run launcher that never touches the GPU),
+    both on GPU 0, gloo for the collectives: shard plan -> per-rank site range -> real HIP kernels
+    through the C-ABI -> rows to rank 0 by the gather AND by peer stores through hipIpc -> bytes equal
+    to the single-GPU call.  fst, batched pairs (config 5), AF front end, extreme scan with windows
+    >= 2^20 sites.  See tests/hip_rank_worker.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "hip_rank_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", script],
+                       capture_output=True, text=True, env=env, timeout=850)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for tag in ("fst gather", "fst peer", "fst auto", "pairs gather", "pairs peer", "af peer", "extreme peer"):
+        assert "HIP_RANKS_OK " + tag in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _genome(seed, n, n_chr):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from synth_genome import SynthGenome
+    return SynthGenome(seed, n, n_chr)
+
+
+def test_full_size_fused_dxy_het_properties(pgt, ctx):
+    """BASELINE config 3 at its full size (10^8 sites, generated on the device): properties that need no oracle.
+    (1) het counts are exact integers: equal to torch's counts on sampled windows and in total over a cover;
+    (2) dxy: neff/nskip equal torch's counts; the window sums of a non-overlapping cover add up to the
+        genome-wide line (pgt_dxy_total) within 1e-9 and its counts exactly;
+    (3) p -> p/2 ... is not exact for dxy, but swapping the two populations is: d(p1,p2) = d(p2,p1) bit for bit;
+    (4) coordinates follow pos and the table exactly; fused == separate entry points bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, n_chr, W, S, minind = 100_000_000, 20, 50_000, 10_000, 5
+    g = _genome(777, n, n_chr)
+    pos = g.pos_t(0, n, dev)
+    p1, p2, n1, n2 = g.dxy_columns_t(0, n, dev)
+    g1, g2 = g.genotype_t(0, 0, n, dev), g.genotype_t(1, 0, n, dev)
+    win = pgt.build_windows_sites(g.run_len, W, S)
+    wt = windows_to_device(win, dev)
+    dxy_out, tot, h1, h2, tree = ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, minind, wt)
+    torch.cuda.synchronize()
+    d = rows_from_device(dxy_out, DXY_ROW_DTYPE)
+    t = rows_from_device(tot, DXY_TOTAL_DTYPE)[0]
+    r1, r2 = rows_from_device(h1, HET_ROW_DTYPE), rows_from_device(h2, HET_ROW_DTYPE)
+    assert d.size == r1.size == r2.size == win.size
+    hpos = pos.cpu().numpy().view(np.uint32)
+    for r in (d, r1, r2):
+        assert np.array_equal(r["start"], hpos[win["lo"]]) and np.array_equal(r["end"], hpos[win["hi"] - 1])
+    assert np.array_equal(r1["mid"], ((r1["start"].astype(np.uint64) + r1["end"]) % 2**32 // 2).astype(np.uint32))
+    ok = (n1 >= minind) & (n2 >= minind)
+    site = p1 * (1.0 - p2) + p2 * (1.0 - p1)
+    for i in np.linspace(0, win.size - 1, 25).astype(int):
+        lo, hi = int(win["lo"][i]), int(win["hi"][i])
+        assert int(d["neff"][i]) == int(ok[lo:hi].sum()) and int(d["nskip"][i]) == hi - lo - int(ok[lo:hi].sum())
+        assert_close([d["sum"][i]], [float(site[lo:hi][ok[lo:hi]].sum())], "dxy window sum")
+        for r, gg in ((r1, g1), (r2, g2)):
+            assert int(r["nonmissing"][i]) == int((gg[lo:hi] >= 0).sum()) and int(r["nhet"][i]) == int((gg[lo:hi] == 1).sum())
+            assert r["h"][i] == int(r["nhet"][i]) / int(r["nonmissing"][i])
+    assert int(t["neff"]) == int(ok.sum()) and int(t["nskip"]) == n - int(ok.sum())
+    assert_close([t["sum"]], [float(site[ok].sum())], "genome-wide dxy")
+    # non-overlapping cover: window sums add up to the totals
+    win_t = pgt.build_windows_sites(g.run_len, W, W)
+    dc, tc, hc1, _, _ = ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, minind, windows_to_device(win_t, dev), tree=tree)
+    torch.cuda.synchronize()
+    dc, hc1 = rows_from_device(dc, DXY_ROW_DTYPE), rows_from_device(hc1, HET_ROW_DTYPE)
+    assert int(dc["neff"].astype(np.int64).sum()) == int(t["neff"]) and int(dc["nskip"].astype(np.int64).sum()) == int(t["nskip"])
+    assert_close([dc["sum"].sum()], [t["sum"]], "cover dxy")
+    assert int(hc1["nonmissing"].astype(np.int64).sum()) == int((g1 >= 0).sum())
+    assert int(hc1["nhet"].astype(np.int64).sum()) == int((g1 == 1).sum())
+    # populations swapped: the same bits
+    ds, ts, _, _, _ = ctx.dxy_het_reduce_dev(pos, p2, p1, n2, n1, g1, g2, minind, wt, tree=tree)
+    torch.cuda.synchronize()
+    assert rows_from_device(ds, DXY_ROW_DTYPE).tobytes() == d.tobytes() and rows_from_device(ts, DXY_TOTAL_DTYPE).tobytes() == np.array([t]).tobytes()
+    # fused == separate
+    so, st, _ = ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, minind, wt)
+    ho, _ = ctx.het_reduce_dev(pos, g2, wt)
+    torch.cuda.synchronize()
+    assert rows_from_device(so, DXY_ROW_DTYPE).tobytes() == d.tobytes() and rows_from_device(ho, HET_ROW_DTYPE).tobytes() == r2.tobytes()
+
+
+def test_full_size_28_pairs_properties(pgt, ctx):
+    """BASELINE config 5 at its full size in the one-GPU form: 8 populations = 28 pairs x 10^8 sites, one
+    table, one batched call.  pairs == singles bit for bit on 3 sampled pairs; exact x2 linearity on
+    every pair; a non-overlapping cover adds up to each pair's genome total; coordinates."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, n_chr, W, S, n_pairs = 100_000_000, 20, 50_000, 10_000, 28
+    g = _genome(888, n, n_chr)
+    pos = g.pos_t(0, n, dev)
+    al, bl = [], []
+    for p in range(n_pairs):
+        a_, b_ = g.pair_columns_t(p, 0, n, dev)
+        al.append(a_)
+        bl.append(b_)
+    win = pgt.build_windows_sites(g.run_len, W, S)
+    wt = windows_to_device(win, dev)
+    out, tree = ctx.fst_reduce_pairs_dev(pos, al, bl, wt)
+    torch.cuda.synchronize()
+    rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+    hpos = pos.cpu().numpy().view(np.uint32)
+    for p in range(n_pairs):
+        assert np.array_equal(rows[p]["start"], hpos[win["lo"]]) and np.array_equal(rows[p]["end"], hpos[win["hi"] - 1])
+        assert np.array_equal(rows[p]["n"], (win["hi"] - win["lo"]).astype(np.uint32))
+    for p in (0, 13, 27):
+        single, _ = ctx.fst_reduce_dev(pos, al[p], bl[p], wt)
+        torch.cuda.synchronize()
+        assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
+        for i in np.linspace(0, win.size - 1, 9).astype(int):
+            lo, hi = int(win["lo"][i]), int(win["hi"][i])
+            assert_close([rows[p]["asum"][i]], [float(al[p][lo:hi].sum())], "asum sample")
+            assert_close([rows[p]["bsum"][i]], [float(bl[p][lo:hi].sum())], "bsum sample")
+    for t in al + bl:
+        t.mul_(2.0)
+    out2, _ = ctx.fst_reduce_pairs_dev(pos, al, bl, wt, tree=tree)
+    torch.cuda.synchronize()
+    rows2 = rows_from_device(out2, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+    assert np.array_equal(rows2["asum"], 2.0 * rows["asum"]) and np.array_equal(rows2["bsum"], 2.0 * rows["bsum"])
+    assert np.array_equal(rows2["fst"], rows["fst"])
+    win_t = pgt.build_windows_sites(g.run_len, W, W)
+    outc, _ = ctx.fst_reduce_pairs_dev(pos, al, bl, windows_to_device(win_t, dev), tree=tree)
+    torch.cuda.synchronize()
+    rc = rows_from_device(outc, FST_ROW_DTYPE).reshape(n_pairs, win_t.size)
+    for p in range(n_pairs):
+        assert int(rc[p]["n"].astype(np.int64).sum()) == n
+        assert_close([rc[p]["bsum"].sum()], [float(bl[p].sum())], f"cover bsum pair {p}")
+        assert_close([rc[p]["asum"].sum()], [float(al[p].sum())], f"cover asum pair {p}")
+
+
+@pytest.mark.parametrize("n_pairs", [33, 70])
+def test_more_pairs_than_one_launch_batch(pgt, ctx, n_pairs):
+    """More than 32 pairs: launch_fst walks the pairs in batches of 32 (tree and row offsets of the later
+    batches); every pair equals its single call bit for bit."""
+    import torch
+    rng = np.random.default_rng(100 + n_pairs)
+    n = 70_001
+    chr_ids, pos = synth.chromosomes(rng, n, 3, equal=False)
+    cols = [synth.fst_columns(rng, n) for _ in range(n_pairs)]
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 9_000, 2_000)
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(pos.view(np.int32)).to(dev)
+    ta = [torch.from_numpy(c[0]).to(dev) for c in cols]
+    tb = [torch.from_numpy(c[1]).to(dev) for c in cols]
+    out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+    for p in range(n_pairs):
+        assert rows[p].tobytes() == ctx.fst_reduce(pos, cols[p][0], cols[p][1], win).tobytes(), p
+
+
+def test_extreme_sharded_equals_single_with_long_windows(pgt, ctx):
+    """Extreme-score scan shard by shard (pgt_plan_shards) with windows of >= 2^20 sites, so that the 2^14-
+    and 2^20-site tree nodes are in play: concatenated shards == the single call, bit for bit."""
+    import torch
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS, PGT_EXT_XP_MIN
+    from popgenomicstools_amd.distributed import shard_windows
+    dev = torch.device("cuda:0")
+    n = 6_000_000
+    g = _genome(999, n, 1)
+    pos, a, _ = g.fst_columns_t(0, n, dev)
+    score = a * 40.0 - 2.0
+    hpos = pos.cpu().numpy().view(np.uint32)
+    win = pgt.build_windows_extreme(hpos, g.run_len, None, 35_000_000)
+    assert int((win["hi"] - win["lo"]).max()) >= 1 << 20
+    for mode, cut in ((PGT_EXT_IHS, 2.0), (PGT_EXT_XP_MIN, -1.5)):
+        single, _ = ctx.extreme_reduce_dev(pos, score, mode, cut, windows_to_device(win, dev))
+        torch.cuda.synchronize()
+        single = rows_from_device(single, EXT_ROW_DTYPE)
+        for world in (2, 3, 5):
+            parts = []
+            for rank in range(world):
+                s, local, _ = shard_windows(win, rank, world)
+                if local.size == 0:
+                    continue
+                lo, hi = int(s["site_lo"]), int(s["site_hi"])
+                assert lo % (1 << 20) == 0
+                o, _ = ctx.extreme_reduce_dev(pos[lo:hi], score[lo:hi], mode, cut, windows_to_device(local, dev))
+                torch.cuda.synchronize()
+                parts.append(rows_from_device(o, EXT_ROW_DTYPE))
+            assert np.concatenate(parts).tobytes() == single.tobytes(), (mode, world)
+
+
+def test_device_wrappers_reject_short_buffers(pgt, ctx):
+    """A short column or an undersized out / tree buffer is an error in the binding, not a device overrun."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 10_000
+    pos = torch.arange(1, n + 1, dtype=torch.int32, device=dev)
+    a = torch.rand(n, dtype=torch.float64, device=dev)
+    win = windows_to_device(pgt.build_windows_sites(np.array([n], dtype=np.uint64), 1000, 500), dev)
+    with pytest.raises(_lib.PgtError):
+        ctx.fst_reduce_dev(pos[:-1], a, a, win)
+    with pytest.raises(_lib.PgtError):
+        ctx.fst_reduce_dev(pos, a, a, win, out=torch.empty(40, dtype=torch.uint8, device=dev))
+    with pytest.raises(_lib.PgtError):
+        ctx.fst_reduce_dev(pos, a, a, win, tree=torch.empty(256, dtype=torch.uint8, device=dev))
+    # an empty shard (a rank that owns no window) is a no-op, not an error
+    e64, e32 = torch.empty(0, dtype=torch.float64, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
+    out, _ = ctx.fst_reduce_dev(e32, e64, e64, torch.empty(0, dtype=torch.uint8, device=dev))
+    assert out.numel() == 0
+
+
+def test_entry_points_leave_the_callers_device_alone(pgt, ctx):
+    """pgt_open and the reduce calls run on the ctx's device and restore the caller's current device
+    (one visible GPU here: the check is that the current device is still 0 and torch keeps working)."""
+    import torch
+    before = torch.cuda.current_device()
+    c2 = pgt.Context(0)
+    c2.close()
+    assert torch.cuda.current_device() == before
+    assert float(torch.ones(4, device="cuda").sum()) == 4.0

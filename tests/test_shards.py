@@ -39,14 +39,17 @@ def test_plan_shards_alignment_follows_window_length(pgt):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_gather_matches_single(tmp_path):
-    """world_size 2 over gloo on CPU: each rank reduces its shard (the per-rank reduce is played by
-    the oracle here — the GPU is absent), rows are gathered to rank 0 exactly as bench.py does,
-    and the assembled table equals the single-rank one."""
+@pytest.mark.parametrize("world,port", [(2, 29531), (3, 29532)])
+def test_gloo_ranks_match_single(tmp_path, world, port):
+    """world_size 2 and 3 over gloo on CPU: each rank reduces its shard (the per-rank reduce is played
+    by a numpy loop here — the GPU is absent), rows travel to the destination rank through the
+    product's RowExchange (gather transport), and the assembled table equals the oracle's; also a
+    rank without windows, two tables per window, and (3 ranks) a sub-group with dst != global rank 0."""
     script = os.path.join(ROOT, "tests", "gloo_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531", script, str(tmp_path)],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GLOO_OK" in r.stdout
+    for tag in ["GLOO_OK sharded_scan", "GLOO_OK tables", "GLOO_OK empty-shard"] + (["GLOO_OK subgroup"] if world >= 3 else []):
+        assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
