@@ -202,6 +202,16 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
  * hint only affects speed: a longer window is still answered correctly from the levels that
  * exist.  The host-buffer entry points derive it from the table themselves. */
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
+/* Typical distance, in sites, between the starts of consecutive windows of the following *_dev calls
+ * (the tools' step size S); 0 (the default) = unknown.  With a step of at most 32 sites the queries
+ * use the SLIDING strategy: one wave answers a group of consecutive windows from one suffix scan of
+ * the sites around their starts, one prefix scan around their ends and ONE tree query for the
+ * interior they share, instead of one tree query per window — the regime of `-winsize W -stepsize 1`
+ * (fstWindow.cpp:80-83,95-99: the reference re-sums W sites and shifts W-S per window there).  Speed
+ * only: any table is answered correctly whatever the hint (groups that do not slide fall back to the
+ * per-window query); sums are taken in a different order, so the last bits of a float may differ
+ * between the two strategies.  The host-buffer entry points derive the hint from the table. */
+int pgt_set_window_step(pgt_ctx *ctx, uint64_t step_sites);
 
 /* ---- per-kernel timing (HIP events on the launch stream; for bench.py's roofline) ------- */
 /* When enabled, the *_dev entry points bracket the tree-build kernel and the window-query

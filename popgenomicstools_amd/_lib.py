@@ -43,7 +43,7 @@ SYMBOLS = [
     "pgt_extreme_reduce", "pgt_extreme_reduce_dev",
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
-    "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
+    "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
     "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
 ]
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.pgt_af_tree_bytes.argtypes = [u32, u64]
     lib.pgt_fst_af_reduce_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
     lib.pgt_set_max_window.argtypes = [vp, u64]
+    lib.pgt_set_window_step.argtypes = [vp, u64]
     lib.pgt_set_profiling.argtypes = [vp, i32]
     lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pgt_plan_shards.argtypes = [vp, u64, u32, vp]

@@ -119,8 +119,9 @@ __device__ __forceinline__ void af_accumulate(double *vals, const double *f) {
         }
 }
 
+template <int V>
 __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int v, uint64_t i) {
-    return reinterpret_cast<double *>(tv.base + tv.off[level_slot] + (size_t)v * tv.stride[level_slot]) + i;
+    return reinterpret_cast<double *>(tv.base + tv.off[level_slot]) + i * V + v;  // node-major: V doubles per node
 }
 
 // ---- BUILD: one wave per level-2 tile (64 leaf tiles of 128 sites) ------------------------------
@@ -136,12 +137,12 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int my = rs_my_index<V>(lane);
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
-    // Level-1 nodes are staged in LDS and written as whole 512-byte rows once per level-2 tile (the
-    // first version stored each leaf total straight from the lane that held it: 36 scattered 8-byte
-    // stores per 128-site tile at 8 populations).  Measured: a timing-only build with no level-1 stores
-    // runs at 76.9 % of the HBM peak at 8 populations, scattered stores 59.6 %, row stores 61.7 % — as in
-    // fst_build_kernel what costs is node writes interleaved in time with the read stream, and here they
-    // are 3.5 % of the bytes with LDS room for one tile per wave only, so they cannot be deferred further.
+    // Level-1 nodes are staged in LDS and leave once per level-2 tile as ONE contiguous block (node-major
+    // tree: 64 nodes x V doubles = 18 KiB at 8 populations).  History, 8 populations, % of the HBM peak:
+    // each leaf total stored straight from the lane that held it (36 scattered 8-byte stores per 128-site
+    // tile) 59.6; value-major tree with one 512-byte row per value and tile (36 rows in 36 different
+    // arrays) 57-62; a timing-only build without level-1 stores 76.9.  As in fst_build_kernel what costs
+    // is node writes interleaved with the read stream, here 3.5 % of the bytes.
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
     double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kWave;
 
@@ -179,17 +180,26 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             af_accumulate<NP>(vals, fy);
             rs_steps<V, 0>(vals, lane);
             if (my >= 0) {
-                stage[my * kWave + j] = vals[0];  // row `my` of the wave's LDS stage, column = leaf tile
+                stage[j * V + my] = vals[0];  // node j of the wave's LDS stage: V consecutive doubles (conflict-free)
                 l2acc += vals[0];
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
         }
-        if (my >= 0) *af_node(tv, 1, my, t) = l2acc;
-        // the 64 level-1 nodes of every value: one coalesced 512-byte row each (the stage belongs to
-        // this wave alone, LDS operations of a wave complete in order: no barrier)
+        if (my >= 0) *af_node<V>(tv, 1, my, t) = l2acc;  // the level-2 node: V consecutive doubles, one 8*V-byte run
+        // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
+        // (the stage belongs to this wave alone, LDS operations of a wave complete in order: no barrier)
+        {
+            double2 *dst = reinterpret_cast<double2 *>(af_node<V>(tv, 0, 0, t * kRadix));
+            const double2 *src = reinterpret_cast<const double2 *>(stage);
+            constexpr int kVec = V * kWave / 2;  // double2 elements of the block
 #pragma unroll 4
-        for (int v = 0; v < V; ++v) __builtin_nontemporal_store(stage[v * kWave + lane], af_node(tv, 0, v, t * kRadix + lane));
+            for (int e = lane; e < kVec; e += kWave) {
+                const double2 w = src[e];
+                __builtin_nontemporal_store(w.x, &dst[e].x);
+                __builtin_nontemporal_store(w.y, &dst[e].y);
+            }
+        }
     }
 }
 
@@ -198,12 +208,14 @@ __global__ __launch_bounds__(256) void af_up_kernel(AfTree tv, int child_slot, u
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const int v = blockIdx.y;
+    const int v = blockIdx.y, V = tv.n_vals;
+    const double *child = reinterpret_cast<const double *>(tv.base + tv.off[child_slot]);
+    double *parent = reinterpret_cast<double *>(tv.base + tv.off[child_slot + 1]);
     for (uint64_t p = wave0; p < n_parent; p += n_waves) {
         const uint64_t i = p * kRadix + lane;
-        double x = i < n_child ? *af_node(tv, child_slot, v, i) : 0.0;
+        double x = i < n_child ? child[i * V + v] : 0.0;
         x = wave_sum(x);
-        if (lane == 0) *af_node(tv, child_slot + 1, v, p) = x;
+        if (lane == 0) parent[p * V + v] = x;
     }
 }
 
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32
         auto sum_nodes = [&](int level, uint64_t from, uint64_t to) {
             for (uint64_t i = from + lane; i < to; i += kWave) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] += *af_node(tv, level - 1, v, i);
+                for (int v = 0; v < V; ++v) acc[v] += *af_node<V>(tv, level - 1, v, i);
             }
         };
         uint64_t clo = lo, chi = hi;
@@ -342,11 +354,11 @@ int init_af_kernels(std::string *err) {
 
 int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops, uint64_t n,
                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream, void *ev_build0,
-                  void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window) {
+                  void *ev_build1, void *ev_query1, std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
     const int n_vals = (int)(n_pops + n_pops * (n_pops - 1) / 2);
-    const AfTree tv = af_tree_view(tl, n_vals, tree, useful_levels(tl, PGT_STAT_FST, max_window));
+    const AfTree tv = af_tree_view(tl, n_vals, tree, useful_levels(tl, PGT_STAT_FST, hints.max_window));
     AfCols cols{};
     for (uint32_t k = 0; k < n_pops; ++k) { cols.f[k] = freq[k]; cols.nsamp[k] = nsamp[k]; }
     switch (n_pops) {

@@ -3,6 +3,7 @@
 // There is deliberately no CPU code path here: without a HIP device every reduce fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -15,7 +16,7 @@ struct pgt_ctx {
     std::string error;
     bool profiling = false;
     bool have_timing = false;
-    uint64_t max_window = 0;  // pgt_set_max_window hint (0 = unknown)
+    pgt::Hints hints;  // pgt_set_max_window / pgt_set_window_step (0 = unknown)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // build start, build end, query end
 };
 
@@ -53,14 +54,26 @@ struct DevBuf {
 // RAII: the host-buffer entry points know the table, so they set the max-window hint themselves
 struct HintScope {
     pgt_ctx *ctx;
-    uint64_t saved;
-    HintScope(pgt_ctx *c, const pgt_win *win, uint64_t n_win) : ctx(c), saved(c->max_window) {
+    pgt::Hints saved;
+    HintScope(pgt_ctx *c, const pgt_win *win, uint64_t n_win) : ctx(c), saved(c->hints) {
         uint64_t m = 1;
         for (uint64_t i = 0; i < n_win; ++i)
             if (win[i].hi >= win[i].lo && win[i].hi - win[i].lo > m) m = win[i].hi - win[i].lo;
-        c->max_window = m;
+        c->hints.max_window = m;
+        // typical step = median distance between consecutive window starts (a sample from the middle of the
+        // table: chromosome boundaries and the Q1 carry make a few distances irregular)
+        std::vector<uint64_t> d;
+        const uint64_t from = n_win > 4097 ? n_win / 2 - 2048 : 0, to = n_win > 4097 ? from + 4096 : (n_win ? n_win - 1 : 0);
+        for (uint64_t i = from; i < to; ++i)
+            if (win[i + 1].lo >= win[i].lo) d.push_back(win[i + 1].lo - win[i].lo);
+        uint64_t step = 0;
+        if (!d.empty()) {
+            std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
+            step = d[d.size() / 2];
+        }
+        c->hints.window_step = step;
     }
-    ~HintScope() { ctx->max_window = saved; }
+    ~HintScope() { ctx->hints = saved; }
 };
 
 int check_windows_host(pgt_ctx *ctx, const pgt_win *win, uint64_t n_win, uint64_t n, bool need_coords_or_sites) {
@@ -192,7 +205,13 @@ int pgt_set_profiling(pgt_ctx *ctx, int enabled) {
 
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites) {
     if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
-    ctx->max_window = max_window_sites;
+    ctx->hints.max_window = max_window_sites;
+    return PGT_OK;
+}
+
+int pgt_set_window_step(pgt_ctx *ctx, uint64_t step_sites) {
+    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+    ctx->hints.window_step = step_sites;
     return PGT_OK;
 }
 
@@ -219,7 +238,7 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
     if (!aligned16(tree) || tree_bytes < (size_t)n_pairs * pgt_tree_bytes(PGT_STAT_FST, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
-    return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
+    return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
 }
 
 int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
@@ -239,7 +258,7 @@ int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_HET, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
-    return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
+    return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
 }
 
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
@@ -256,7 +275,7 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_dxy(pos, p1, p2, n1, n2, n, minind, win, n_win, out, tot, tree, stream, e.b0, e.b1, e.q1,
-                      &ctx->error, ctx->max_window);
+                      &ctx->error, ctx->hints);
 }
 
 int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
@@ -275,7 +294,7 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_dxy_het(pos, p1, p2, n1, n2, g1, g2, n, minind, win, n_win, dxy_out, tot, het_out1, het_out2, tree,
-                          stream, e.b0, e.b1, e.q1, &ctx->error, ctx->max_window);
+                          stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
 }
 
 size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites) {
@@ -300,7 +319,7 @@ int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_fst_af(pos, freq, nsamp, n_pops, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
-                         ctx->max_window);
+                         ctx->hints);
 }
 
 int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
@@ -316,7 +335,7 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
         return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: tree workspace too small or misaligned");
     const EvSet e = events_for(ctx);
     return launch_ext(pos, score, n, mode, cutoff, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
-                      ctx->max_window);
+                      ctx->hints);
 }
 
 /* ---------------- multi-GPU row exchange ---------------- */

@@ -79,57 +79,72 @@ inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
     return useful_levels_for(t, (uint64_t)leaf_sites(stat), max_window);
 }
 
-// ---- allele-frequency front end (pgt_af_kernels.hip): V scalar trees, structure-of-arrays -----
+// ---- allele-frequency front end (pgt_af_kernels.hip): nodes of V scalar sums, node-major ------
+// A node is V consecutive doubles (V = NP + NP(NP-1)/2), the nodes of a level are contiguous: the 64
+// level-1 nodes a build wave finishes together are ONE contiguous block of 512*V bytes (18 KiB at 8
+// populations), and a query lane reads a node as one contiguous run.
 constexpr int kAfMaxPops = 8;
 struct AfTree {
     char *base;
-    size_t off[kMaxLevels];     // byte offset of level slot k (all V value arrays of that level)
-    size_t stride[kMaxLevels];  // bytes between consecutive value arrays inside level slot k
+    size_t off[kMaxLevels];  // byte offset of level slot k
     int n_levels;
+    int n_vals;              // V: doubles per node
 };
-inline size_t af_level_stride(const TreeLayout &t, int k) { return ((t.count[k] * 8 + 255) / 256) * 256; }
+inline size_t af_level_bytes(const TreeLayout &t, int k, int n_vals) { return ((t.count[k] * (size_t)n_vals * 8 + 255) / 256) * 256; }
 inline size_t af_tree_bytes(const TreeLayout &t, int n_vals) {
     size_t b = 0;
-    for (int k = 0; k < t.n_levels; ++k) b += (size_t)n_vals * af_level_stride(t, k);
+    for (int k = 0; k < t.n_levels; ++k) b += af_level_bytes(t, k, n_vals);
     return b;
 }
 inline AfTree af_tree_view(const TreeLayout &t, int n_vals, void *tree, int levels) {
     AfTree v{};
     v.base = static_cast<char *>(tree);
     v.n_levels = levels;
+    v.n_vals = n_vals;
     size_t off = 0;
     for (int k = 0; k < t.n_levels; ++k) {
         v.off[k] = off;
-        v.stride[k] = af_level_stride(t, k);
-        off += (size_t)n_vals * v.stride[k];
+        off += af_level_bytes(t, k, n_vals);
     }
     return v;
+}
+
+// Speed-only hints of a context (pgt_set_max_window, pgt_set_window_step); 0 = unknown.
+struct Hints {
+    uint64_t max_window = 0;   // longest window in sites: tree levels with larger nodes are not built
+    uint64_t window_step = 0;  // typical distance between consecutive window starts: selects the sliding query
+};
+// Windows per wave of the sliding query for a given step (0 or 1 = the one-wave-per-window query).
+inline uint32_t slide_group(uint64_t step) {
+    if (step == 0 || step > 32) return 1;
+    const uint64_t g = 128 / step + 1;
+    return (uint32_t)(g > 64 ? 64 : g);
 }
 
 // ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
-               void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
+               void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
 int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
                pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
-               void *ev_query1, std::string *err, uint64_t max_window);
+               void *ev_query1, std::string *err, const Hints &hints);
 int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, void *stream, void *ev_build0,
-               void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
+               void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
 
 int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                    const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
                    const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
                    pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, void *stream,
-                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
+                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
 
 int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
                uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
-               void *ev_query1, std::string *err, uint64_t max_window);
+               void *ev_query1, std::string *err, const Hints &hints);
 int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops,
                   uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
-                  void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window);
+                  void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
 
 int init_kernels(std::string *err);     // pgt_kernels.hip: one-time kernel attributes (called by pgt_open)
 int init_af_kernels(std::string *err);  // pgt_af_kernels.hip

@@ -357,7 +357,6 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
 // cutoff} per 256 sites, level-2 per 16384 sites.                                 8 B/site read.
 // ------------------------------------------------------------------------------------------
 struct ExtBuildArgs { const double *s; int mode; double thr; };
-__global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv);
 
 // ------------------------------------------------------------------------------------------
 // Upper levels (only exist when level 2 has more than 64 nodes): parent = Σ of 64 children.
@@ -533,43 +532,80 @@ struct ExtTraits {
     static __device__ __forceinline__ void store_total(pgt_dxy_total *, const Node &) {}
 };
 
+// One 256-site leaf tile -> its NodeExt, wave-uniform.  The wave owns 4 keys per lane, site offsets
+// h*128 + 2*lane + {0,1} (h = 0,1).  Instead of carrying {key, idx, count} through a three-field
+// butterfly (six steps of 4 cross-lane moves + a two-level compare), only the KEY is max-reduced across
+// lanes; the count is four ballots + s_bcnt1 and the first site attaining the maximum comes from four
+// equality ballots + s_ff1 — scalar instructions on wave-uniform masks, no cross-lane traffic.
+// Semantics are those of node_add (ties -> smallest site index; a NaN key never wins; a tile without
+// any comparable key stays the identity {-inf, none}); the result is bit-identical to the butterfly's.
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_f64<kDppQuadXor1>(v));
+    v = fmax(v, dpp_f64<kDppQuadXor2>(v));
+    v = fmax(v, dpp_f64<kDppRowHalfMirror>(v));
+    v = fmax(v, dpp_f64<kDppRowMirror>(v));
+    v = fmax(v, __shfl_xor(v, 16, kWave));
+    v = fmax(v, __shfl_xor(v, 32, kWave));
+    return v;
+}
+__device__ __forceinline__ NodeExt ext_leaf_tile(const double (&k)[4], bool (&valid)[4], double thr, uint64_t tile0, int lane) {
+    const double ninf = -__builtin_huge_val();
+    uint32_t count = 0;
+    double m = ninf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        count += (uint32_t)__popcll(__ballot(valid[q] && k[q] > thr));
+        m = fmax(m, valid[q] ? k[q] : ninf);  // fmax drops a NaN operand (v_max_f64)
+    }
+    const double wmax = wave_max(m);
+    unsigned long long eq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) eq[q] = __ballot(valid[q] && k[q] == wmax);
+    uint32_t idx = 0xFFFFFFFFu;
+    double key = ninf;
+    const unsigned long long m0 = eq[0] | eq[1], m1 = eq[2] | eq[3];
+    if (m0 != 0) {  // wave-uniform: the first half of the tile holds the first occurrence
+        const int L = __ffsll((long long)m0) - 1;
+        idx = (uint32_t)(tile0 + 2 * (uint64_t)L + (((eq[0] >> L) & 1ull) ? 0 : 1));
+        key = wmax;
+    } else if (m1 != 0) {
+        const int L = __ffsll((long long)m1) - 1;
+        idx = (uint32_t)(tile0 + 2 * kWave + 2 * (uint64_t)L + (((eq[2] >> L) & 1ull) ? 0 : 1));
+        key = wmax;
+    }
+    (void)lane;
+    return NodeExt{key, idx, count};
+}
+
+constexpr int kExtStage = 16;  // tiles staged per wave (16 KiB of LDS): 64 KiB per workgroup -> 2 per CU, as the fst build
+template <int STAGE = kExtStage, int UNROLL = 4, bool DEFER = true>
 __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv) {
+    extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     NodeExt *__restrict__ l1 = reinterpret_cast<NodeExt *>(tv.base + tv.off[0]);
     NodeExt *__restrict__ l2 = reinterpret_cast<NodeExt *>(tv.base + tv.off[1]);
     constexpr uint64_t kTile2 = (uint64_t)kLeafExt * kRadix;  // 16384 sites
-    // Node stores are NOT deferred here: this kernel spends more instructions per byte (argmax combine
-    // over three fields) and needs the full 32 waves per CU; with the 64-KiB stage (8 waves per CU) it
-    // fell from 69 % to 60 % of the HBM peak (profiles/r01/measure_configs_1e9.md history).
-    auto site = [&](double s, uint64_t i) {
-        const double k = ExtTraits::key_of(s, g.mode);
-        return NodeExt{k, (uint32_t)i, (uint32_t)(k > g.thr)};
-    };
+    NodeStage<NodeExt, STAGE, true> stage(lds_stage, threadIdx.x >> 6, lane, l1, l2, n_waves);
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
         NodeExt keep = node_identity<NodeExt>();
         if (base + kTile2 <= n) {
             const double2 *__restrict__ ps = reinterpret_cast<const double2 *>(g.s + base);
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += 4) {
-                double2 v[4][2];  // leaf tile = 256 sites = two 1-KiB wave loads; 8 loads in flight per lane
+            for (int j = 0; j < kRadix; j += UNROLL) {
+                double2 v[UNROLL][2];  // leaf tile = 256 sites = two 1-KiB wave loads; 2*UNROLL loads in flight per lane
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) v[u][h] = load16<true>(ps + ((j + u) * 2 + h) * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t t0 = base + (uint64_t)(j + u) * kLeafExt;
-                    NodeExt a = node_identity<NodeExt>();
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {  // 4 sites per lane, combined before any cross-lane step
-                        const uint64_t i0 = t0 + (uint64_t)h * 2 * kWave + 2 * lane;
-                        node_add(a, site(v[u][h].x, i0));
-                        node_add(a, site(v[u][h].y, i0 + 1));
-                    }
-                    a = node_wave_sum(a);
+                for (int u = 0; u < UNROLL; ++u) {
+                    const double k[4] = {ExtTraits::key_of(v[u][0].x, g.mode), ExtTraits::key_of(v[u][0].y, g.mode),
+                                         ExtTraits::key_of(v[u][1].x, g.mode), ExtTraits::key_of(v[u][1].y, g.mode)};
+                    bool valid[4] = {true, true, true, true};
+                    const NodeExt a = ext_leaf_tile(k, valid, g.thr, base + (uint64_t)(j + u) * kLeafExt, lane);
                     if (lane == j + u) keep = a;
                 }
             }
@@ -577,19 +613,27 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t
             for (int j = 0; j < kRadix; ++j) {
                 const uint64_t tile0 = base + (uint64_t)j * kLeafExt;
                 if (tile0 >= n) break;  // wave-uniform
-                NodeExt a = node_identity<NodeExt>();
+                double k[4];
+                bool valid[4];
+#pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint64_t i = tile0 + (uint64_t)(q >> 1) * 2 * kWave + 2 * lane + (q & 1);
-                    if (i < n) node_add(a, site(g.s[i], i));
+                    valid[q] = i < n;
+                    k[q] = valid[q] ? ExtTraits::key_of(g.s[i], g.mode) : 0.0;
                 }
-                a = node_wave_sum(a);
+                const NodeExt a = ext_leaf_tile(k, valid, g.thr, tile0, lane);
                 if (lane == j) keep = a;
             }
         }
-        l1[t * kRadix + lane] = keep;
-        const NodeExt tot = node_wave_sum(keep);
-        if (lane == 0) l2[t] = tot;
+        if constexpr (DEFER) {
+            stage.put(t, keep);
+        } else {
+            l1[t * kRadix + lane] = keep;
+            const NodeExt tot = node_wave_sum(keep);
+            if (lane == 0) l2[t] = tot;
+        }
     }
+    if constexpr (DEFER) stage.flush();
 }
 
 template <class Tr>
@@ -644,6 +688,31 @@ __device__ __forceinline__ void ragged_pair(typename Tr::Node &acc, const typena
     }
 }
 
+// Wave-wide reduction of the site range [lo,hi): every lane returns a partial (node_wave_sum of it is
+// the range's node).  The accumulation order depends on the range only, never on the window table.
+template <class Tr>
+__device__ __forceinline__ typename Tr::Node range_partial(const typename Tr::Cols &c, const char *tree, const TreeView &tv,
+                                                           uint64_t lo, uint64_t hi, int lane, uint64_t n_sites) {
+    typename Tr::Node acc = node_identity<typename Tr::Node>();
+    uint64_t clo = lo, chi = hi;  // current range, in nodes of level k (level 0 = sites)
+    for (int k = 0;; ++k) {
+        if (k == tv.n_levels) {  // top level: whatever is left
+            sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
+            break;
+        }
+        const uint64_t r = k == 0 ? (uint64_t)Tr::kLeaf : (uint64_t)kRadix;
+        const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
+        if (ulo >= uhi) {  // no whole parent inside: finish at this level
+            sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
+            break;
+        }
+        ragged_pair<Tr>(acc, c, tree, tv, k, clo, ulo * r, uhi * r, chi, lane, n_sites);  // < r nodes per side
+        clo = ulo;
+        chi = uhi;
+    }
+    return acc;
+}
+
 template <class Tr>
 __device__ __forceinline__ void query_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
                                            const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
@@ -667,24 +736,7 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
         // clamp to the columns so that a corrupt table can never fault the GPU
         const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
         const uint64_t lo = wd.lo < hi ? wd.lo : hi;
-        typename Tr::Node acc = node_identity<typename Tr::Node>();
-        uint64_t clo = lo, chi = hi;  // current range, in nodes of level k (level 0 = sites)
-        for (int k = 0;; ++k) {
-            if (k == tv.n_levels) {  // top level: whatever is left
-                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
-                break;
-            }
-            const uint64_t r = k == 0 ? (uint64_t)Tr::kLeaf : (uint64_t)kRadix;
-            const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
-            if (ulo >= uhi) {  // no whole parent inside: finish at this level
-                sum_level<Tr>(acc, c, tree, tv, k, clo, chi, lane, n_sites);
-                break;
-            }
-            ragged_pair<Tr>(acc, c, tree, tv, k, clo, ulo * r, uhi * r, chi, lane, n_sites);  // < r nodes per side
-            clo = ulo;
-            chi = uhi;
-        }
-        acc = node_wave_sum(acc);
+        const typename Tr::Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, lo, hi, lane, n_sites));
         if (lane == 0) {
             if (is_total) {
                 Tr::store_total(tot, acc);
@@ -695,6 +747,172 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
                     end = hi > lo ? pos[hi - 1] : 0u;
                 }
                 Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// QUERY, sliding form (pgt_set_window_step <= 32): one wave answers `group` CONSECUTIVE windows, one per
+// lane.  A window [lo,hi) is split at the 128-site grid:
+//     [lo, A)   the rest of lo's 128-site tile      -> a SUFFIX scan of that tile, shared by the group
+//     [A, B)    whole tiles                         -> ONE wave-wide range query per distinct (A,B) of the
+//                                                     group (at step 1: 2-3 per 64 windows)
+//     [B, hi)   the start of hi's tile              -> a PREFIX scan of that tile, shared by the group
+// so a group costs 4 tiles of sites (the two tiles under its starts, the two under its ends) plus a few
+// tree queries instead of one tree query (~3.3 KB of ragged reads) per window: the regime of
+// `-winsize W -stepsize 1`, where the reference re-sums W sites per window (fstWindow.cpp:80-83) and
+// shifts W-S (fstWindow.cpp:95-99).  Each of the three pieces is computed in an order that depends on
+// the window alone (whole-tile scans in a fixed lane order; the interior by range_partial), never on
+// which other windows share the wave: rows are bitwise independent of the grouping, hence of the
+// number of GPUs a table is sharded over.  Windows that do not fit the pattern (shorter than two
+// tiles, or starting/ending outside the group's two tiles) are answered one by one as in query_body.
+// ------------------------------------------------------------------------------------------
+constexpr int kSlideTile = 128;
+template <class Node>
+__device__ __forceinline__ Node node_from_lane(const Node &v, int src_lane) {
+    constexpr int kWords = sizeof(Node) / 4;
+    uint32_t w[kWords];
+    __builtin_memcpy(w, &v, sizeof(Node));
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) w[k] = (uint32_t)__shfl((int)w[k], src_lane, kWave);
+    Node o;
+    __builtin_memcpy(&o, w, sizeof(Node));
+    return o;
+}
+// exclusive scans over the lanes in a fixed (Hillis-Steele) order; `up` = sum of the lanes ABOVE
+template <class Node, bool UP>
+__device__ __forceinline__ Node lane_scan_exclusive(Node v, int lane) {
+    const Node none = node_identity<Node>();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int src = UP ? lane + d : lane - d;
+        const Node t = node_from_lane(v, src & (kWave - 1));
+        Node add = (src >= 0 && src < kWave) ? t : none;
+        node_add(v, add);
+    }
+    const int nb = UP ? lane + 1 : lane - 1;  // inclusive -> exclusive: take the neighbour's inclusive value
+    const Node t = node_from_lane(v, nb & (kWave - 1));
+    return (nb >= 0 && nb < kWave) ? t : none;
+}
+
+template <class Tr>
+__device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
+                                                 const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
+                                                 typename Tr::Row *__restrict__ out, uint64_t n_sites, pgt_dxy_total *tot,
+                                                 int pair, uint32_t group, char *lds) {
+    using Node = typename Tr::Node;
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const typename Tr::Cols c = Tr::cols(args, pair);
+    const char *tree = tv.base + (size_t)pair * tv.pair_stride;
+    const uint64_t n_groups = (n_win + group - 1) / group;
+    const uint64_t n_tasks = n_groups + (tot ? 1 : 0);
+    // this wave's scan tables: [side: 0 suffix under the starts, 1 prefix under the ends][tile 0,1][site]
+    Node *span = reinterpret_cast<Node *>(lds) + (size_t)wib * 4 * kSlideTile;
+    const Node none = node_identity<Node>();
+    // Scan of one whole 128-site tile, lane l owning its sites 2l and 2l+1, always in the same order:
+    // side 0: dst[x] = sum of the tile's sites x .. 127;  side 1: dst[x] = sum of its sites 0 .. x.
+    auto scan_tile = [&](int side, uint64_t tile, Node *dst) {
+        const uint64_t i0 = tile * kSlideTile + 2 * (uint64_t)lane;
+        const Node v0 = i0 < n_sites ? Tr::leaf(c, i0) : none;
+        const Node v1 = i0 + 1 < n_sites ? Tr::leaf(c, i0 + 1) : none;
+        Node pairsum = v0;
+        node_add(pairsum, v1);
+        if (side == 0) {
+            Node s1 = lane_scan_exclusive<Node, true>(pairsum, lane);  // lanes above
+            node_add(s1, v1);
+            Node s0 = s1;
+            node_add(s0, v0);
+            dst[2 * lane + 1] = s1;
+            dst[2 * lane] = s0;
+        } else {
+            Node p0 = lane_scan_exclusive<Node, false>(pairsum, lane);  // lanes below
+            node_add(p0, v0);
+            Node p1 = p0;
+            node_add(p1, v1);
+            dst[2 * lane] = p0;
+            dst[2 * lane + 1] = p1;
+        }
+    };
+
+    for (uint64_t task = wave0; task < n_tasks; task += n_waves) {
+        if (task == n_groups) {  // the genome-wide total (dxy)
+            const Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, 0, n_sites, lane, n_sites));
+            if (lane == 0) Tr::store_total(tot, acc);
+            continue;
+        }
+        const uint64_t w = task * group + (uint64_t)lane;
+        const bool active = (uint32_t)lane < group && w < n_win;
+        pgt_win wd;
+        wd.lo = wd.hi = 0; wd.flags = PGT_WIN_COORDS; wd.start = wd.end = 0; wd.label_run = 0;
+        if (active) wd = win[w];
+        const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
+        const uint64_t lo = wd.lo < hi ? wd.lo : hi;
+        const uint64_t tl = lo / kSlideTile, th = hi / kSlideTile;
+        const uint32_t offl = (uint32_t)(lo % kSlideTile), offh = (uint32_t)(hi % kSlideTile);
+        // the group's first start tile / end tile (wave-uniform)
+        uint64_t tl0 = active ? tl : ~0ull, th0 = active ? th : ~0ull;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint64_t a = __shfl_xor(tl0, d, kWave), b = __shfl_xor(th0, d, kWave);
+            tl0 = a < tl0 ? a : tl0;
+            th0 = b < th0 ? b : th0;
+        }
+        // scans of the two tiles under the starts (suffix) and the two under the ends (prefix)
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                scan_tile(side, (side ? th0 : tl0) + (uint64_t)k, span + (side * 2 + k) * kSlideTile);
+        // the wave's own LDS rows: LDS operations of one wave complete in order, no barrier needed
+        const uint64_t A = offl ? (tl + 1) * kSlideTile : lo, B = th * kSlideTile;
+        const bool fast = active && hi > lo && tl - tl0 <= 1 && th - th0 <= 1 && A <= B;
+        Node left = none, right = none;
+        if (fast && offl) left = span[(0 * 2 + (int)(tl - tl0)) * kSlideTile + offl];
+        if (fast && offh) right = span[(1 * 2 + (int)(th - th0)) * kSlideTile + offh - 1];
+        uint32_t start = wd.start, end = wd.end;
+        if (active && !(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
+            start = hi > lo ? pos[lo] : 0u;
+            end = hi > lo ? pos[hi - 1] : 0u;
+        }
+        typename Tr::Row *row = out + (uint64_t)pair * n_win + w;
+        bool pending = fast;
+        for (unsigned long long m = __ballot(pending); m != 0; m = __ballot(pending)) {
+            const int L = __ffsll((long long)m) - 1;
+            const uint64_t Au = __shfl(A, L, kWave), Bu = __shfl(B, L, kWave);
+            const Node mid = node_wave_sum(range_partial<Tr>(c, tree, tv, Au, Bu, lane, n_sites));
+            if (pending && A == Au && B == Bu) {
+                Node total = left;
+                node_add(total, mid);
+                node_add(total, right);
+                Tr::finish(row, total, start, end, lo, hi, c, pos);
+                pending = false;
+            }
+        }
+        // windows outside the group's tiles: the same three pieces from scans of their own tiles; windows
+        // shorter than the split allows (A > B) or empty: the plain range query.  Either way the order
+        // of the sums depends on the window alone.
+        bool slow = active && !fast;
+        for (unsigned long long m = __ballot(slow); m != 0; m = __ballot(slow)) {
+            const int L = __ffsll((long long)m) - 1;
+            const uint64_t lo_u = __shfl(lo, L, kWave), hi_u = __shfl(hi, L, kWave);
+            const uint64_t Au = __shfl(A, L, kWave), Bu = __shfl(B, L, kWave);
+            Node acc;
+            if (hi_u > lo_u && Au <= Bu) {  // wave-uniform
+                const uint32_t ol = (uint32_t)(lo_u % kSlideTile), oh = (uint32_t)(hi_u % kSlideTile);
+                if (ol) scan_tile(0, lo_u / kSlideTile, span);
+                if (oh) scan_tile(1, hi_u / kSlideTile, span + 2 * kSlideTile);
+                acc = ol ? span[ol] : none;
+                node_add(acc, node_wave_sum(range_partial<Tr>(c, tree, tv, Au, Bu, lane, n_sites)));
+                node_add(acc, oh ? span[2 * kSlideTile + oh - 1] : none);
+            } else {
+                acc = node_wave_sum(range_partial<Tr>(c, tree, tv, lo_u, hi_u, lane, n_sites));
+            }
+            if (lane == L) {
+                Tr::finish(row, acc, start, end, lo, hi, c, pos);
+                slow = false;
             }
         }
     }
@@ -725,19 +943,46 @@ __global__ __launch_bounds__(256) void dxy_het_query_kernel(DxyHetQueryArgs f, c
     }
 }
 
+template <class Tr>
+__global__ __launch_bounds__(256) void query_slide_kernel(typename Tr::Args args, const uint32_t *pos, TreeView tv,
+                                                          const pgt_win *win, uint64_t n_win, typename Tr::Row *out,
+                                                          uint64_t n_sites, pgt_dxy_total *tot, uint32_t group) {
+    extern __shared__ __attribute__((aligned(16))) char lds_span[];
+    query_slide_body<Tr>(args, pos, tv, win, n_win, out, n_sites, tot, (int)blockIdx.y, group, lds_span);
+}
+__global__ __launch_bounds__(256) void dxy_het_query_slide_kernel(DxyHetQueryArgs f, const uint32_t *pos, const pgt_win *win,
+                                                                  uint64_t n_win, uint64_t n_sites, uint32_t group) {
+    extern __shared__ __attribute__((aligned(16))) char lds_span[];
+    if (blockIdx.y == 0) {
+        query_slide_body<DxyTraits>(f.dxy, pos, f.tv_dxy, win, n_win, f.dxy_out, n_sites, f.tot, 0, group, lds_span);
+    } else {
+        const int k = blockIdx.y - 1;
+        query_slide_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0,
+                                    group, lds_span);
+    }
+}
+constexpr size_t kSlideLdsBytes = (size_t)4 * 4 * kSlideTile * 16;  // 4 waves x 4 tiles x 128 nodes of <= 16 B
+
 inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     if (e == hipSuccess) return PGT_OK;
     if (err) *err = std::string(what) + ": " + hipGetErrorString(e);
     return PGT_EDEVICE;
 }
 
-inline unsigned build_grid(uint64_t n_l2, unsigned cap = 2048) {
-    // 4 waves per 256-thread workgroup, one level-2 tile per wave-iteration; at the default cap
-    // (8 resident workgroups per CU x 256 CUs) the rest is grid-strided.
-    uint64_t blocks = (n_l2 + 3) / 4;
-    if (cap && blocks > cap) blocks = cap;
+inline unsigned build_grid(uint64_t n_items, unsigned cap = 2048) {
+    // 4 waves per 256-thread workgroup, one work item (level-2 tile) per wave-iteration, at most `cap`
+    // workgroups (what is resident at once); the rest is grid-strided.  The grid is BALANCED: with
+    // r = ceil(items / (4 cap)) rounds, only ceil(items / r) waves are launched, so every wave does r
+    // items (the last few r - 1) instead of some waves doing one item more than the others while the
+    // rest of the chip idles — 7.45 rounds cost 8 either way, but 15259 items over 1908 waves finish
+    // together (1.25e8 sites, the per-GPU shard of the 8-GPU run: +7 %).
+    if (cap == 0) cap = 1u << 28;
+    if (n_items == 0) return 1;
+    const uint64_t max_waves = (uint64_t)cap * 4;
+    const uint64_t rounds = (n_items + max_waves - 1) / max_waves;
+    const uint64_t waves = (n_items + rounds - 1) / rounds;
+    uint64_t blocks = (waves + 3) / 4;
     if (blocks > (1u << 30)) blocks = 1u << 30;
-    if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
 }
 
@@ -790,7 +1035,7 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 // attribute call can fall inside a caller's stream capture.
 int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function attributes are per device
     const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>), reinterpret_cast<const void *>(dxy_build_kernel),
-                            reinterpret_cast<const void *>(dxy_het_build_kernel)};
+                            reinterpret_cast<const void *>(dxy_het_build_kernel), reinterpret_cast<const void *>(ext_build_kernel<>)};
     for (const void *k : staged)
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
                               "hipFuncSetAttribute", err))
@@ -800,10 +1045,10 @@ int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function
 
 int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
                uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
-               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, uint64_t max_window) {
+               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
-    const int levels = useful_levels(tl, PGT_STAT_FST, max_window);
+    const int levels = useful_levels(tl, PGT_STAT_FST, hints.max_window);
     for (uint32_t p0 = 0; p0 < n_pairs; p0 += kMaxPairs) {
         const uint32_t np = n_pairs - p0 < (uint32_t)kMaxPairs ? n_pairs - p0 : (uint32_t)kMaxPairs;
         PairCols cols{};
@@ -825,8 +1070,13 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         if (p0 + np >= n_pairs) if (int rc = record(ev_build1, s, err)) return rc;
         if (n_win > 0) {
             FstTraits::Args args{cols};
-            hipLaunchKernelGGL(query_kernel<FstTraits>, dim3(query_grid(n_win), np), dim3(256), 0, s, args, pos,
-                               tv, win, n_win, out + (uint64_t)p0 * n_win, n, (pgt_dxy_total *)nullptr);
+            if (const uint32_t group = slide_group(hints.window_step); group > 1)
+                hipLaunchKernelGGL(query_slide_kernel<FstTraits>, dim3(query_grid((n_win + group - 1) / group), np), dim3(256),
+                                   kSlideLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
+                                   (pgt_dxy_total *)nullptr, group);
+            else
+                hipLaunchKernelGGL(query_kernel<FstTraits>, dim3(query_grid(n_win), np), dim3(256), 0, s, args, pos,
+                                   tv, win, n_win, out + (uint64_t)p0 * n_win, n, (pgt_dxy_total *)nullptr);
             if (int rc = hip_fail(hipGetLastError(), "query_kernel<fst>", err)) return rc;
         }
     }
@@ -835,10 +1085,10 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
 
 int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
                pgt_het_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1,
-               std::string *err, uint64_t max_window) {
+               std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_HET, n);
-    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_HET, max_window));
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_HET, hints.max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);
@@ -849,8 +1099,12 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0) {
         HetTraits::Args args{g};
-        hipLaunchKernelGGL(query_kernel<HetTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win,
-                           n_win, out, n, (pgt_dxy_total *)nullptr);
+        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+            hipLaunchKernelGGL(query_slide_kernel<HetTraits>, dim3(query_grid((n_win + group - 1) / group)), dim3(256),
+                               kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr, group);
+        else
+            hipLaunchKernelGGL(query_kernel<HetTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win,
+                               n_win, out, n, (pgt_dxy_total *)nullptr);
         if (int rc = hip_fail(hipGetLastError(), "query_kernel<het>", err)) return rc;
     }
     return record(ev_query1, s, err);
@@ -859,11 +1113,11 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
 int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
                uint64_t n, int minind, const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
                void *tree, void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err,
-               uint64_t max_window) {
+               const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_DXY, n);
     // the genome-wide total is a query over [0,n): it wants every level
-    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : max_window));
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : hints.max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1], kFstBuildBlocks)), dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n,
@@ -874,24 +1128,52 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0 || tot) {
         DxyTraits::Args args{p1, p2, n1, n2, minind};
-        hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
-                           win, n_win, out, n, tot);
+        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+            hipLaunchKernelGGL(query_slide_kernel<DxyTraits>, dim3(query_grid((n_win + group - 1) / group + 1)), dim3(256),
+                               kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, tot, group);
+        else
+            hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
+                               win, n_win, out, n, tot);
         if (int rc = hip_fail(hipGetLastError(), "query_kernel<dxy>", err)) return rc;
     }
     return record(ev_query1, s, err);
 }
 
+// grid = exactly the workgroups that are resident together (LDS-limited), so that all waves run in near
+// lockstep and their staged node rows are flushed at about the same times (see NodeStage)
+template <int STAGE, int UNROLL, bool DEFER>
+void launch_ext_variant(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv, unsigned cap) {
+    const size_t lds = DEFER ? (size_t)4 * STAGE * 1024 : 0;
+    hipLaunchKernelGGL((ext_build_kernel<STAGE, UNROLL, DEFER>), dim3(build_grid(n_l2, cap)), dim3(256), lds, s, g, n, n_l2, tv);
+}
+void launch_ext_build(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv) {
+#ifdef PGT_TUNING_BUILD  // tools/tune_ext.py: A/B of the stage depth / occupancy / loads in flight
+    static const int variant = getenv("PGT_EXT_VARIANT") ? atoi(getenv("PGT_EXT_VARIANT")) : 0;
+    const char *e = getenv("PGT_EXT_VARIANT_NOW");  // re-read per call for interleaved A/B in one process
+    const int v = e ? atoi(e) : variant;
+    switch (v) {
+        case 1: return launch_ext_variant<8, 4, false>(s, g, n, n_l2, tv, 2048);
+        case 2: return launch_ext_variant<8, 4, true>(s, g, n, n_l2, tv, 1024);
+        case 3: return launch_ext_variant<4, 4, true>(s, g, n, n_l2, tv, 2048);
+        case 4: return launch_ext_variant<8, 8, true>(s, g, n, n_l2, tv, 1024);
+        case 5: return launch_ext_variant<8, 2, true>(s, g, n, n_l2, tv, 1024);
+        case 6: return launch_ext_variant<8, 8, false>(s, g, n, n_l2, tv, 2048);
+        default: break;
+    }
+#endif
+    launch_ext_variant<kExtStage, 4, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
+}
+
 int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
                uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
-               void *ev_query1, std::string *err, uint64_t max_window) {
+               void *ev_query1, std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_EXT, n);
-    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_EXT, max_window));
+    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_EXT, hints.max_window));
     const double thr = mode == PGT_EXT_XP_MIN ? -cutoff : cutoff;  // s < cutoff  <=>  -s > -cutoff
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(ext_build_kernel, dim3(build_grid(tl.count[1])), dim3(256), 0, s,
-                           ExtBuildArgs{score, mode, thr}, n, tl.count[1], tv);
+        launch_ext_build(s, ExtBuildArgs{score, mode, thr}, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "ext_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeExt>(tl, tv, 1, s, err)) return rc;
     }
@@ -909,12 +1191,12 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
                    const int8_t *g1, const int8_t *g2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
                    pgt_dxy_row *dxy_out, pgt_dxy_total *tot, pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree,
                    void *stream, void *ev_build0, void *ev_build1, void *ev_query1, std::string *err,
-                   uint64_t max_window) {
+                   const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout td = tree_layout(PGT_STAT_DXY, n), th = tree_layout(PGT_STAT_HET, n);
     char *base = static_cast<char *>(tree);
-    const int lh = useful_levels(th, PGT_STAT_HET, max_window);
-    const TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, tot ? 0 : max_window));
+    const int lh = useful_levels(th, PGT_STAT_HET, hints.max_window);
+    const TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, tot ? 0 : hints.max_window));
     const TreeView tvh0 = make_view(th, base + td.bytes, th.bytes, lh);
     const TreeView tvh1 = make_view(th, base + td.bytes + th.bytes, th.bytes, lh);
     if (int rc = record(ev_build0, s, err)) return rc;
@@ -932,7 +1214,11 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
     if (n_win > 0 || tot) {
         DxyHetQueryArgs q{DxyTraits::Args{p1, p2, n1, n2, minind}, {g1, g2}, tvd, {tvh0, tvh1}, dxy_out, tot,
                           {het_out1, het_out2}};
-        hipLaunchKernelGGL(dxy_het_query_kernel, dim3(query_grid(n_win + 1), 3), dim3(256), 0, s, q, pos, win, n_win, n);
+        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+            hipLaunchKernelGGL(dxy_het_query_slide_kernel, dim3(query_grid((n_win + group - 1) / group + 1), 3), dim3(256),
+                               kSlideLdsBytes, s, q, pos, win, n_win, n, group);
+        else
+            hipLaunchKernelGGL(dxy_het_query_kernel, dim3(query_grid(n_win + 1), 3), dim3(256), 0, s, q, pos, win, n_win, n);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_query_kernel", err)) return rc;
     }
     return record(ev_query1, s, err);

@@ -403,6 +403,11 @@ class Context:
         """Performance hint for the *_dev calls: no window is longer than `sites` (0 = unknown)."""
         self._check(self._lib.pgt_set_max_window(self._ctx, int(sites)))
 
+    def set_window_step(self, sites: int):
+        """Performance hint for the *_dev calls: consecutive windows start `sites` apart (0 = unknown);
+        steps of at most 32 sites select the sliding query (include/pgtwin.h)."""
+        self._check(self._lib.pgt_set_window_step(self._ctx, int(sites)))
+
     # ---- per-kernel timing ------------------------------------------------------------------
     def set_profiling(self, enabled: bool):
         self._check(self._lib.pgt_set_profiling(self._ctx, int(enabled)))

@@ -933,3 +933,66 @@ def test_entry_points_leave_the_callers_device_alone(pgt, ctx):
     c2.close()
     assert torch.cuda.current_device() == before
     assert float(torch.ones(4, device="cuda").sum()) == 4.0
+
+
+# ---------------------------------------------------------------------------------------------
+# sliding query (pgt_set_window_step <= 32)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,S", [(1, 1), (2, 1), (5, 2), (127, 1), (128, 1), (129, 3), (300, 1), (5_000, 1), (5_000, 7),
+                                 (50_000, 1), (50_000, 32), (1_000, 31)])
+def test_sliding_query_vs_oracle(pgt, ctx, oracle, W, S):
+    """S << W: the host API derives the step hint from the table and takes the sliding query; every
+    statistic against the oracle (ints exact, floats 1e-9), on ragged chromosome layouts (short
+    chromosomes exercise the per-window fallback inside a group)."""
+    rng = np.random.default_rng(W * 131 + S)
+    n = 60_000 if W >= 5_000 else 9_000
+    for n_chr in (1, 4, 37):
+        chr_ids, pos = synth.chromosomes(rng, n, n_chr, equal=False)
+        a, b = synth.fst_columns(rng, n)
+        check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S)
+        g = synth.het_column(rng, n)
+        check_het(pgt, ctx, oracle, chr_ids, pos, g, W, S)
+        p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+        check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, 5, 1, 0)
+
+
+def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt, ctx):
+    """Device API: with the step hint (sliding) and without (one wave per window) the integer columns
+    are identical and the sums agree to 1e-9; het rows are bitwise equal (integer sums); and the sliding
+    rows do not depend on how the table is cut into shards (bitwise)."""
+    import torch
+    from popgenomicstools_amd.distributed import shard_windows
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(404)
+    n = 700_000
+    chr_ids, pos = synth.chromosomes(rng, n, 6, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n).astype(np.int8)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    tp, ta, tb, tg = t(pos.view(np.int32)), t(a), t(b), t(g)
+    for W, S in ((50_000, 1), (10_000, 3), (777, 16)):
+        win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+        wt = windows_to_device(win, dev)
+        ctx.set_window_step(0)
+        std, _ = ctx.fst_reduce_dev(tp, ta, tb, wt)
+        hstd, _ = ctx.het_reduce_dev(tp, tg, wt)
+        ctx.set_window_step(S)
+        sl, _ = ctx.fst_reduce_dev(tp, ta, tb, wt)
+        hsl, _ = ctx.het_reduce_dev(tp, tg, wt)
+        torch.cuda.synchronize()
+        r0, r1 = rows_from_device(std, FST_ROW_DTYPE), rows_from_device(sl, FST_ROW_DTYPE)
+        for f in ("start", "end", "mid", "n"):
+            assert np.array_equal(r0[f], r1[f]), f
+        assert_close(r1["asum"], r0["asum"], "asum")
+        assert_close(r1["bsum"], r0["bsum"], "bsum")
+        assert rows_from_device(hstd, HET_ROW_DTYPE).tobytes() == rows_from_device(hsl, HET_ROW_DTYPE).tobytes()
+        for world in (2, 5):
+            parts = []
+            for rank in range(world):
+                s_, local, _ = shard_windows(win, rank, world)
+                lo, hi = int(s_["site_lo"]), int(s_["site_hi"])
+                o, _ = ctx.fst_reduce_dev(tp[lo:hi], ta[lo:hi], tb[lo:hi], windows_to_device(local, dev))
+                torch.cuda.synchronize()
+                parts.append(rows_from_device(o, FST_ROW_DTYPE))
+            assert np.concatenate(parts).tobytes() == r1.tobytes(), (W, S, world)
+    ctx.set_window_step(0)
