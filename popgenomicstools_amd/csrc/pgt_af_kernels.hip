@@ -128,7 +128,7 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 // (Tried: 256-site leaf tiles so that the reduce-scatter runs half as often: no gain at 8
 // populations, 53.6 % vs 56.7 % of HBM peak.  The kernel is bound by the 2 x (NP*3 + pairs*2) f64
 // operations per lane and tile and by occupancy — 188 VGPRs, 2 waves per SIMD — not by the exchanges.)
-template <int NP>
+template <int NP, int ABLATE = 0>  // ABLATE (tuning build only, wrong results): 1 no reduce-scatter, 2 no node stores, 3 no accumulate
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
 
@@ -176,9 +176,19 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             double fx[NP], fy[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
-            af_accumulate<NP>(vals, fx);
-            af_accumulate<NP>(vals, fy);
-            rs_steps<V, 0>(vals, lane);
+            if constexpr (ABLATE != 3) {
+                af_accumulate<NP>(vals, fx);
+                af_accumulate<NP>(vals, fy);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) vals[k] = fx[k] + fy[k];
+            }
+            if constexpr (ABLATE != 1) {
+                rs_steps<V, 0>(vals, lane);
+            } else {  // keeps every value (and every load) alive without any cross-lane step
+#pragma unroll
+                for (int v = 1; v < V; ++v) vals[0] += vals[v];
+            }
             if (my >= 0) {
                 stage[j * V + my] = vals[0];  // node j of the wave's LDS stage: V consecutive doubles (conflict-free)
                 l2acc += vals[0];
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
         }
         if (my >= 0) *af_node<V>(tv, 1, my, t) = l2acc;  // the level-2 node: V consecutive doubles, one 8*V-byte run
+        if constexpr (ABLATE == 2) continue;
         // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
         // (the stage belongs to this wave alone, LDS operations of a wave complete in order: no barrier)
         {
@@ -314,9 +325,27 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
     };
     if (int rc = rec(ev_b0)) return rc;
     if (n > 0) {
-        uint64_t blocks = (tl.count[1] + 3) / 4;
-        if (blocks > 2048) blocks = 2048;
+        // Balanced grid-stride over the level-2 tiles: r = ceil(tiles / (4 cap)) rounds, ceil(tiles / r) waves,
+        // so every wave does r tiles.  Measured at 10^8 sites, 8 populations (profiles/r02/af_caps.txt): the
+        // unbalanced 2048-workgroup grid of round 1 (12207 tiles over 8192 waves: half the waves do 2 tiles,
+        // half 1) 68-69 % of the HBM peak, balanced 74.9 %; caps of 512 / 1024 workgroups 70.8 / 74.0 %.
+        uint64_t cap = NP == 2 ? 512 : 2048;
+#ifdef PGT_TUNING_BUILD
+        if (const char *capenv = getenv("PGT_AF_CAP")) cap = (uint64_t)atoi(capenv);
+#endif
+        const uint64_t max_waves = cap * 4;
+        const uint64_t rounds = (tl.count[1] + max_waves - 1) / max_waves;
+        const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
+        uint64_t blocks = (waves + 3) / 4;
         constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kWave * sizeof(double);  // 4 waves x V rows x 512 B
+#ifdef PGT_TUNING_BUILD
+        const char *ab = getenv("PGT_AF_ABLATE");
+        const int abl = ab ? atoi(ab) : 0;
+        if (abl == 1) hipLaunchKernelGGL((af_build_kernel<NP, 1>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        else if (abl == 2) hipLaunchKernelGGL((af_build_kernel<NP, 2>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        else if (abl == 3) hipLaunchKernelGGL((af_build_kernel<NP, 3>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        else
+#endif
         hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
         for (int k = 2; k < tv.n_levels; ++k) {
