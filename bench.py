@@ -141,6 +141,48 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
     out["pairs28_1e8"] = dict(r, config="BASELINE configs[4], one-GPU form: fstWindow 28 pop-pairs x 1e8 sites batched",
                               kernel="fst_build_kernel (grid.y = 28)")
+    del al, bl
+    # the same 28 pairs from 8 allele-frequency columns: 64 B/site instead of 448
+    fr = [g8.freq_t(k, 0, n8, dev) for k in range(8)]
+    nsamp = [10.0 + k for k in range(8)]
+    af_tree = torch.empty(int(pgt._lib.load().pgt_af_tree_bytes(8, n8)), dtype=torch.uint8, device=dev)
+    r = timed_config(ctx, lambda: ctx.fst_af_reduce_dev(pos, fr, nsamp, win, out=rows, tree=af_tree), 64.0 * n8, reps=8)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["af8_pairs28_1e8"] = dict(r, config="SURVEY 8(f2): 28 pairs from 8 allele-frequency columns x 1e8 sites (WCFst on device)",
+                                  kernel="af_build_kernel<8>")
+    del fr, af_tree
+    # ihsWindow-style extreme-score scan: one f64 score column, 100 kb windows
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS, PGT_STAT_EXT
+    ewin_h = pgt.build_windows_extreme(pos.cpu().numpy().view(np.uint32), g8.run_len, None, 100_000)
+    ewin = windows_to_device(ewin_h, dev)
+    erows = torch.empty(ewin_h.size * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    score = a * 40.0 - 2.0
+    ctx.set_max_window(int((ewin_h["hi"] - ewin_h["lo"]).max()))
+    r = timed_config(ctx, lambda: ctx.extreme_reduce_dev(pos, score, PGT_EXT_IHS, 2.0, ewin, out=erows, tree=tree_pool), 8.0 * n8)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["ihs_extreme_1e8"] = dict(r, config="SURVEY 8(f3): ihsWindow-style extreme-score scan, 1e8 sites, 100 kb windows",
+                                  kernel="ext_build_kernel")
+    del score
+    # S << W (fstWindow W=50000, S=1) on 10^7 sites: the sliding query against the per-window query
+    n7 = 10_000_000
+    win1_h = pgt.build_windows_sites(np.array([n7], dtype=np.uint64), W, 1)
+    win1 = windows_to_device(win1_h, dev)
+    rows1 = torch.empty(win1_h.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    ctx.set_max_window(W)
+    q = {}
+    for name, hint in (("per_window", 0), ("sliding", 1)):
+        ctx.set_window_step(hint)
+        ctx.set_profiling(True)
+        t = []
+        for _ in range(4):
+            ctx.fst_reduce_dev(pos[:n7], a[:n7], b[:n7], win1, out=rows1, tree=tree_pool)
+            t.append(ctx.last_kernel_ms()[1])
+        ctx.set_profiling(False)
+        q[name] = float(np.median(t[1:]))
+    ctx.set_window_step(0)
+    out["fst_1e7_step1_query"] = {"config": "fstWindow 1e7 sites, W=50000, S=1 (9.95e6 windows): query kernel only",
+                                  "query_ms_per_window_strategy": q["per_window"], "query_ms_sliding_strategy": q["sliding"],
+                                  "windows": int(win1_h.size)}
     return out
 
 
