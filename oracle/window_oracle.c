@@ -573,6 +573,29 @@ int orc_write_het_text(const char *path, const uint32_t *chr, const uint32_t *po
     return fclose(f) ? ORC_EIO : ORC_OK;
 }
 
+/* ANGSD .mafs text: header + `chr pos major minor ref freq nind` (the seven columns Mafsite reads,
+ * dxyWindow.cpp:24-32; only chr, pos, freq, nind matter). */
+int orc_write_maf_text(const char *path, const uint32_t *chr, const uint32_t *pos, const double *freq,
+                       const int32_t *nind, size_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return ORC_EIO;
+    static char buf[1 << 16];
+    setvbuf(f, buf, _IOFBF, sizeof buf);
+    fputs("chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd\n", f);
+    char line[160];
+    for (size_t i = 0; i < n; ++i) {
+        char *p = line;
+        memcpy(p, "chr", 3); p += 3;
+        p = put_u32(p, chr[i] + 1); *p++ = '\t';
+        p = put_u32(p, pos[i]);
+        memcpy(p, "\tA\tC\tA\t", 7); p += 7;
+        p = put_fixed6(p, freq[i]); *p++ = '\t';
+        p = put_u32(p, (uint32_t)nind[i]); *p++ = '\n';
+        fwrite(line, 1, (size_t)(p - line), f);
+    }
+    return fclose(f) ? ORC_EIO : ORC_OK;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Path-based wrappers (ctypes cannot hand over a FILE*)
  * ---------------------------------------------------------------------------------------- */

@@ -123,6 +123,8 @@ int orc_dxy_text_path(const char *maf1, const char *maf2, const char *sizefile, 
                       const char *err_path);
 
 /* Fast text writers for synthetic inputs (bench cpu_baseline leg, golden generation). */
+int orc_write_maf_text(const char *path, const uint32_t *chr, const uint32_t *pos, const double *freq,
+                       const int32_t *nind, size_t n);
 int orc_write_fst_text(const char *path, const uint32_t *chr, const uint32_t *pos,
                        const double *a, const double *b, size_t n);
 int orc_write_het_text(const char *path, const uint32_t *chr, const uint32_t *pos,

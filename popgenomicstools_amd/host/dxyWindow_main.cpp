@@ -178,6 +178,7 @@ int main(int argc, char **argv) {
 
     timer.lap("sync + table");
     pgt_ctx *ctx = device.get();
+    timer.lap("wait for HIP");
     std::vector<pgt_dxy_row> rows(win.size());
     pgt_dxy_total tot{};
     check(pgt_dxy_reduce(ctx, pos.data(), p1.data(), p2.data(), n1.data(), n2.data(), pos.size(), minind, win.data(),
@@ -190,9 +191,8 @@ int main(int argc, char **argv) {
         return (size_t)std::sprintf(o, "%s\t%u\t%u\t%g\t%u\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
                                     rows[i].end, rows[i].sum, rows[i].neff, rows[i].nskip);
     });
-    timer.lap("print");
     // genome-wide line: stdout for the global run, stderr beside windows (dxyWindow.cpp:429-433)
     std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff,
                  (unsigned long long)tot.nskip);
-    return 0;
+    finish(timer);
 }

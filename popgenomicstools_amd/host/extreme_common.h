@@ -84,6 +84,7 @@ inline int run_extreme(const char *path, bool skip_header, int score_field, uint
     check(pgt_build_windows_extreme(tab.pos.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, win.data(), win.size(), &n_win), nullptr);
     timer.lap("window table");
     pgt_ctx *ctx = device.get();
+    timer.lap("wait for HIP");
     std::vector<pgt_ext_row> rows(n_win);
     check(pgt_extreme_reduce(ctx, tab.pos.data(), tab.score.data(), n, mode, cutoff, win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");
@@ -95,8 +96,7 @@ inline int run_extreme(const char *path, bool skip_header, int score_field, uint
                                         (double)(int)r.nbig / r.nsites, r.nsites);
         return (size_t)std::sprintf(o, "%s\t%u\t%u\tNA\tNA\tNA\t0\n", chr, r.start, r.end);
     });
-    timer.lap("print");
-    return 0;
+    finish(timer);
 }
 
 }  // namespace pgthost

@@ -55,9 +55,10 @@ int main(int argc, char **argv) {
     std::vector<pgt_win> win(n_win);
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
 
+    timer.lap("window table");
     pgt_ctx *ctx = device.get();
     std::vector<pgt_het_row> rows(n_win);
-    timer.lap("window table");
+    timer.lap("wait for HIP");
     check(pgt_het_reduce(ctx, tab.pos.data(), tab.g.data(), n, win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");
 
@@ -66,6 +67,5 @@ int main(int argc, char **argv) {
         return (size_t)std::sprintf(o, "%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
                                     rows[i].end, rows[i].mid, rows[i].h, rows[i].nonmissing);
     });
-    timer.lap("print");
-    return 0;
+    finish(timer);
 }

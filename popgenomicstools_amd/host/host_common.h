@@ -52,9 +52,37 @@ inline void check(int rc, const pgt_ctx *ctx) {
 }
 
 // ---- phase timing on stderr when PGT_HOST_TIMING is set ------------------------------------
+// Milliseconds since the kernel created this process (exec, dynamic linking of the HIP runtime and static
+// initialisers included): /proc/self/stat field 22 (start time in clock ticks since boot) against the
+// monotonic clock, which Linux counts from boot as well (minus suspend; irrelevant here).
+inline double process_age_ms() {
+    FILE *f = std::fopen("/proc/self/stat", "r");
+    if (!f) return -1.0;
+    char buf[1024];
+    const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[got] = 0;
+    const char *p = std::strrchr(buf, ')');  // the command name may contain spaces
+    if (!p) return -1.0;
+    unsigned long long start = 0;
+    int field = 2;
+    for (++p; *p && field < 22; ++p)
+        if (*p == ' ') {
+            ++field;
+            if (field == 22) start = std::strtoull(p + 1, nullptr, 10);
+        }
+    if (!start) return -1.0;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (ts.tv_sec + ts.tv_nsec * 1e-9 - (double)start / (double)sysconf(_SC_CLK_TCK)) * 1e3;
+}
+
 struct PhaseTimer {
     bool on = std::getenv("PGT_HOST_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    PhaseTimer() {
+        if (on) std::fprintf(stderr, "[pgt-host] %-14s %9.3f ms\n", "process start", process_age_ms());
+    }
     void lap(const char *what) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -62,6 +90,16 @@ struct PhaseTimer {
         t = now;
     }
 };
+
+// End of a successful run: everything is printed, so skip the teardown (unmapping gigabytes of input
+// text and columns, destroying the HIP runtime: 0.1-0.3 s at 10^8 lines that no user is waiting for).
+[[noreturn]] inline void finish(PhaseTimer &timer) {
+    std::fflush(stdout);
+    timer.lap("print");
+    if (timer.on) std::fprintf(stderr, "[pgt-host] %-14s %9.3f ms\n", "total", process_age_ms());
+    std::fflush(stderr);
+    _exit(0);
+}
 
 // ---- input text: mmap for plain files, zlib for gzip (dxyWindow.cpp:82-83,256-278) ----------
 class Text {

@@ -51,6 +51,44 @@ def main():
             same, t_ref_s, sp = "n/a", "n/a", "n/a"
         phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
         print(f"| {tool} | {t_ref_s} | {t_new:.2f} | {sp} | {len(r_new.stdout.splitlines())} | {same} | {phases} |")
+    # dxyWindow: the reference source needs Boost (absent here), so the CPU side of this row is the oracle's
+    # text front end — our restatement of dxyWindow.cpp's streaming loop ("port"), single-threaded.
+    nd = min(n, 20_000_000)  # two MAF files of ~35 B per line: bounded so that the scratch disk is enough
+    full = (chr_ids, pos)
+    chr_ids, pos = chr_ids[:nd], pos[:nd]
+    p1, p2, n1, n2 = synth.dxy_columns(rng, nd)
+    f_m1, f_m2, f_sz = os.path.join(d, "pop1.mafs"), os.path.join(d, "pop2.mafs"), os.path.join(d, "sizes.txt")
+    orc.write_maf_text(f_m1, chr_ids, pos, p1, n1)
+    orc.write_maf_text(f_m2, chr_ids, pos, p2, n2)
+    lens = np.diff(np.concatenate(([0], np.flatnonzero(np.diff(chr_ids)) + 1, [nd])))
+    ends = np.cumsum(lens) - 1
+    with open(f_sz, "w") as fh:
+        for c, e in enumerate(ends):
+            fh.write(f"chr{c + 1}\t{int(pos[e]) + 1000}\n")
+    for label, opts in (("dxyWindow -fixedsite 1 (50000/10000 sites)", ["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-fixedsite", "1"]),
+                        ("dxyWindow bp (50 kb / 10 kb)", ["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-sizefile", f_sz])):
+        env = dict(os.environ, PGT_HOST_TIMING="1")
+        cmd = [os.path.join(BIN, "dxyWindow")] + opts + [f_m1, f_m2]
+        wall(cmd, env)
+        t_new, r_new = wall(cmd, env)
+        o_out, o_err = os.path.join(d, "orc.out"), os.path.join(d, "orc.err")
+        t0 = time.perf_counter()
+        rc = orc.dxy_text(f_m1, f_m2, f_sz if "-sizefile" in opts else None, 50000, 10000, 5, 1 if "-fixedsite" in opts else 0, 0, o_out, o_err)
+        t_ref = time.perf_counter() - t0
+        assert rc == 0 and r_new.returncode == 0, (rc, r_new.returncode, r_new.stderr[-300:])
+        ref_rows = [ln.split("\t") for ln in open(o_out).read().splitlines()]
+        new_rows = [ln.split("\t") for ln in r_new.stdout.decode().splitlines()]
+        same = len(ref_rows) == len(new_rows) and all(a_[:3] == b_[:3] and a_[4:] == b_[4:] and
+                                                      abs(float(a_[3]) - float(b_[3])) <= 5.1e-6 * abs(float(a_[3])) + 1e-12
+                                                      for a_, b_ in zip(ref_rows, new_rows))
+        phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
+        print(f"| {label}, {nd:.0e} sites x 2 files | {t_ref:.2f} (oracle port, not the reference binary) | {t_new:.2f} | {t_ref / t_new:.1f}x | {len(new_rows)} | "
+              f"{same} (ints exact, sums to 6 digits) | {phases} |")
+        os.unlink(o_out)
+        os.unlink(o_err)
+    for p_ in (f_m1, f_m2, f_sz):
+        os.unlink(p_)
+    chr_ids, pos = full
     # S = 1: one window per site.  The reference re-sums W entries per site (O(N*W)); it is timed on
     # a 10^5-site sample only.
     m, W1 = 2_000_000, 50_000

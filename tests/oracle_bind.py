@@ -126,6 +126,16 @@ class Oracle:
         if rc:
             raise RuntimeError(f"orc_write_fst_text: {rc}")
 
+    def write_maf_text(self, path, chr_ids, pos, freq, nind):
+        c, p = _u32(chr_ids), _u32(pos)
+        fr = np.ascontiguousarray(freq, dtype=np.float64)
+        ni = np.ascontiguousarray(nind, dtype=np.int32)
+        f = self.lib.orc_write_maf_text
+        f.argtypes = [C.c_char_p] + [C.c_void_p] * 4 + [C.c_size_t]
+        rc = f(path.encode(), c.ctypes.data, p.ctypes.data, fr.ctypes.data, ni.ctypes.data, p.size)
+        if rc:
+            raise RuntimeError(f"orc_write_maf_text: {rc}")
+
     def write_het_text(self, path, chr_ids, pos, g):
         c, p = _u32(chr_ids), _u32(pos)
         g = np.ascontiguousarray(g, dtype=np.int32)

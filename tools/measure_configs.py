@@ -13,8 +13,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
 import popgenomicstools_amd as pgt  # noqa: E402
+from synth_genome import SynthGenome  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 
 
@@ -42,7 +42,9 @@ def main():
     chroms, W, S = (40 if big else 20), 50_000, 10_000
     ctx = pgt.Context(0)
     gen = torch.Generator(device=dev).manual_seed(7)
-    pos, a, b, run_len = bench.synth_columns(n, chroms, 12345, dev)
+    genome = SynthGenome(12345, n, chroms)
+    run_len = genome.run_len
+    pos, a, b = genome.fst_columns_t(0, n, dev)
     win = windows_to_device(pgt.build_windows_sites(run_len, W, S), dev)
     print("| config | bytes/site | build ms | GB/s | % of 8 TB/s | query ms | whole step ms | sites/s |")
     print("|---|---|---|---|---|---|---|---|")
@@ -75,12 +77,14 @@ def main():
     eout = torch.empty(ewin_h.size * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     lib = pgt._lib.load()
     import ctypes as C
+    score = a * 40.0 - 2.0
+
     def ext_call():
-        ctx._check(lib.pgt_extreme_reduce_dev(ctx._ctx, pos.data_ptr(), a.data_ptr(), n, 0, 2.0, ewin.data_ptr(), ewin_h.size,
-                                              eout.data_ptr(), tree.data_ptr(), tree.numel(), ctx._stream(None)))
+        ctx.extreme_reduce_dev(pos, score, 0, 2.0, ewin, out=eout, tree=tree)
     ctx.set_max_window(int((ewin_h["hi"] - ewin_h["lo"]).max()))
     row(f"ihsWindow-style extreme scan {n:.0e} ({ewin_h.size} windows)", 8, timed(ctx, ext_call))
     ctx.set_max_window(W)
+    del score
     if big:
         print(f"\n({n:.0e} sites: 28-pair and host-buffer legs skipped)")
         ctx.close()
