@@ -123,12 +123,23 @@ int main(int argc, char **argv) {
     if (m1.n == 0 || m2.n == 0) die("dxyWindow: a MAF file holds no sites");
     if (m1.runs.name[0] != m2.runs.name[0]) die("Chromosomes in MAF files differ");  // dxyWindow.cpp:295-298
 
-    // intersection by (run, position)
+    // The sites common to both files, by (run, position).  Usual case first: both files list exactly the
+    // same sites (ANGSD run on one site list) -> the parsed columns are used as they are, nothing is copied.
     Runs runs;
-    std::vector<uint32_t> pos;
-    std::vector<double> p1, p2;
-    std::vector<int32_t> n1, n2;
-    {
+    std::vector<uint32_t> pos_v;
+    std::vector<double> p1_v, p2_v;
+    std::vector<int32_t> n1_v, n2_v;
+    const uint32_t *pos = nullptr;
+    const double *p1 = nullptr, *p2 = nullptr;
+    const int32_t *n1 = nullptr, *n2 = nullptr;
+    size_t n_sites = 0;
+    const bool same_sites = m1.n == m2.n && m1.runs.name == m2.runs.name && m1.runs.len == m2.runs.len &&
+                            std::memcmp(m1.pos.data(), m2.pos.data(), m1.n * sizeof(uint32_t)) == 0;
+    if (same_sites) {
+        runs = m1.runs;
+        pos = m1.pos.data(); p1 = m1.freq.data(); p2 = m2.freq.data(); n1 = m1.nind.data(); n2 = m2.nind.data();
+        n_sites = m1.n;
+    } else {
         size_t r1 = 0, r2 = 0, o1 = 0, o2 = 0;
         while (r1 < m1.runs.name.size() && r2 < m2.runs.name.size()) {
             const std::string &c1 = m1.runs.name[r1], &c2 = m2.runs.name[r2];
@@ -140,21 +151,24 @@ int main(int argc, char **argv) {
             }
             size_t i = o1, j = o2;
             const size_t e1 = o1 + m1.runs.len[r1], e2 = o2 + m2.runs.len[r2];
+            const size_t before = pos_v.size();
             while (i < e1 && j < e2) {
                 if (m1.pos[i] < m2.pos[j]) ++i;
                 else if (m2.pos[j] < m1.pos[i]) ++j;
                 else {
-                    runs.add(c1.data(), c1.data() + c1.size());
-                    pos.push_back(m1.pos[i]);
-                    p1.push_back(m1.freq[i]); p2.push_back(m2.freq[j]);
-                    n1.push_back(m1.nind[i]); n2.push_back(m2.nind[j]);
+                    pos_v.push_back(m1.pos[i]);
+                    p1_v.push_back(m1.freq[i]); p2_v.push_back(m2.freq[j]);
+                    n1_v.push_back(m1.nind[i]); n2_v.push_back(m2.nind[j]);
                     ++i; ++j;
                 }
             }
+            if (pos_v.size() > before) runs.add(c1.data(), c1.data() + c1.size(), pos_v.size() - before);
             o1 = e1; o2 = e2; ++r1; ++r2;
         }
+        pos = pos_v.data(); p1 = p1_v.data(); p2 = p2_v.data(); n1 = n1_v.data(); n2 = n2_v.data();
+        n_sites = pos_v.size();
     }
-    if (pos.empty()) die("dxyWindow: the two MAF files share no site");
+    if (n_sites == 0) die("dxyWindow: the two MAF files share no site");
 
     std::vector<pgt_win> win;
     if (W > 0) {
@@ -170,9 +184,9 @@ int main(int argc, char **argv) {
                 if (it == chrsize.end()) die("Unable to determine size for " + runs.name[r]);  // dxyWindow.cpp:340-343
                 chr_len[r] = it->second;
             }
-            check(pgt_build_windows_bp(pos.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+            check(pgt_build_windows_bp(pos, runs.len.data(), chr_len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
             win.resize(n_win);
-            check(pgt_build_windows_bp(pos.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+            check(pgt_build_windows_bp(pos, runs.len.data(), chr_len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
         }
     }
 
@@ -181,8 +195,7 @@ int main(int argc, char **argv) {
     timer.lap("wait for HIP");
     std::vector<pgt_dxy_row> rows(win.size());
     pgt_dxy_total tot{};
-    check(pgt_dxy_reduce(ctx, pos.data(), p1.data(), p2.data(), n1.data(), n2.data(), pos.size(), minind, win.data(),
-                         win.size(), rows.data(), &tot), ctx);
+    check(pgt_dxy_reduce(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
     timer.lap("gpu reduce");
 
     // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)
