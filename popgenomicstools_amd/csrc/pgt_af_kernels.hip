@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     // each leaf total stored straight from the lane that held it (36 scattered 8-byte stores per 128-site
     // tile) 59.6; value-major tree with one 512-byte row per value and tile (36 rows in 36 different
     // arrays) 57-62; a timing-only build without level-1 stores 76.9.  As in fst_build_kernel what costs
-    // is node writes interleaved with the read stream, here 3.5 % of the bytes.
+    // is node writes interleaved with the read stream, here 3.5 % of the bytes.  (Round 2, tried and dropped:
+    // requesting the next level-2 tile's first leaf BEFORE the block is stored, so that no load queues
+    // behind 18 KiB of stores in the in-order vmcnt: 69.6 % vs 71.2 % without, 230 VGPRs instead of 188,
+    // profiles/r02/af_pipe.txt.)
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
     double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kWave;
 

@@ -72,9 +72,17 @@ class RowGatherer:
 
     def start(self, local_rows):
         """Asynchronous form: issues the gather and returns its Work handle; the caller must keep
-        `local_rows` untouched until handle.wait() (a stream-level wait) has been issued.  Lets the
-        gather of scan k overlap the build of scan k+1 when the rows are double-buffered."""
+        `local_rows` untouched until handle.wait() (a stream-level wait) has been issued, and — when the
+        counts differ between ranks, i.e. when the rows go through the one staging buffer — must not
+        call start() again before that wait.  RowExchange avoids the staging copy with start_padded()."""
         return self.dist.gather(self._staged(local_rows), self.recv, dst=self.gdst, group=self.group, async_op=True)
+
+    def start_padded(self, padded_rows):
+        """Asynchronous gather of a caller-owned buffer of exactly `width` bytes (its first counts[rank] *
+        row_bytes bytes are the rows): no staging copy, so several gathers may be in flight as long as
+        each has its own buffer."""
+        assert padded_rows.numel() == self.width
+        return self.dist.gather(padded_rows, self.recv, dst=self.gdst, group=self.group, async_op=True)
 
     def __call__(self, local_rows):
         """Returns on dst the list of per-rank row tensors (views, valid until the next call)."""
@@ -144,14 +152,17 @@ class RowExchange:
                 raise PgtError(3, "RowExchange: peer mapping of the row buffer failed on some rank: " + self.peer_error)
             self.mode = "peer" if ok else "gather"
         if self.mode in ("gather", "local"):
-            n = max(self.my_bytes, 1)
             depth = 2 if self.mode == "gather" else 1
-            self.outs = [torch.empty(n, dtype=torch.uint8, device=device)[: self.my_bytes] for _ in range(depth)]
+            self.gatherer = (RowGatherer(self.counts, self.row_bytes, self.coll_device, dst=dst, group=group)
+                             if self.mode == "gather" else None)
+            # each slot is a full-width send buffer whose head is this rank's rows: the kernel writes the rows
+            # where the gather reads them, no staging copy, two gathers in flight never share a buffer
+            width = self.gatherer.width if self.gatherer else max(self.my_bytes, 1)
+            self.bufs = [torch.zeros(width, dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.outs = [b[: self.my_bytes] for b in self.bufs]
             self.pending = [None] * depth
             self.k = 0
             self.last = 0
-            self.gatherer = (RowGatherer(self.counts, self.row_bytes, self.coll_device, dst=dst, group=group)
-                             if self.mode == "gather" else None)
 
     # ---- peer ------------------------------------------------------------------------------
     def _setup_peer(self) -> bool:
@@ -201,11 +212,11 @@ class RowExchange:
 
     def end(self):
         if self.mode == "gather":
-            rows = self.outs[self.k]
+            rows = self.bufs[self.k]
             if self.coll_device != self.device and self.coll_device.type == "cpu":
-                rows = rows.cpu()
+                rows = rows.cpu()  # rehearsal over gloo: CPU staging (synchronises)
             self._host_rows = rows  # keep a staged CPU copy alive until the gather has read it
-            self.pending[self.k] = self.gatherer.start(rows)
+            self.pending[self.k] = self.gatherer.start_padded(rows)
             self.last = self.k
             self.k ^= 1
         elif self.mode == "local":

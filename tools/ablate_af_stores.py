@@ -14,7 +14,7 @@ tree = torch.empty(int(pgt._lib.load().pgt_af_tree_bytes(8, n)), dtype=torch.uin
 out = torch.empty(28 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
 names = {0: "product", 1: "no reduce-scatter (timing only)", 2: "no level-1 stores (timing only)", 3: "no per-site arithmetic (timing only)"}
 variants = (0, 1, 2, 3) if "-DPGT_TUNING_BUILD" in os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "") else (0,)
-caps = [int(x) for x in os.environ.get("AF_CAPS", "512").split(",")]
+caps = [int(x) for x in os.environ.get("AF_CAPS", "2048").split(",")]
 for npop, cap in [(p, c) for p in (8, 4, 2) for c in caps]:
     os.environ["PGT_AF_CAP"] = str(cap)
     print(f"--- grid cap {cap} workgroups")
