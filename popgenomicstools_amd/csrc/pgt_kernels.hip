@@ -101,6 +101,7 @@ struct TreeView {
 constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
+constexpr uint64_t kFstSmallTiles = 40000;            // level-2 tiles (3.3e8 sites) up to which 16 loads per lane are kept in flight
 
 // The per-wave LDS stage shared by the fst, dxy and extreme-score builds (16-byte nodes: 1 KiB per row).
 template <class Node>
@@ -270,6 +271,7 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
     else if (v == -9.0) acc.nskip += 1;
 }
 
+template <int U = 2>  // leaf tiles per batch: 4*U loads in flight per lane (U = 4 for short inputs, see launch_fst)
 __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, const double *__restrict__ p2,
                                                const int32_t *__restrict__ n1, const int32_t *__restrict__ n2,
                                                uint64_t n, int minind, uint64_t n_l2, const TreeView &tv, char *lds_stage) {
@@ -290,18 +292,18 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
             const int2 *__restrict__ m1 = reinterpret_cast<const int2 *>(n1 + base);
             const int2 *__restrict__ m2 = reinterpret_cast<const int2 *>(n2 + base);
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += 2) {
-                double2 x1[2], x2[2];
-                int2 k1[2], k2[2];
+            for (int j = 0; j < kRadix; j += U) {
+                double2 x1[U], x2[U];
+                int2 k1[U], k2[U];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < U; ++u) {
                     x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
                     x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
                     k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
                     k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < U; ++u) {
                     NodeDxy acc{0.0, 0u, 0u};
                     dxy_acc(acc, dxy_site(x1[u].x, x2[u].x, k1[u].x, k2[u].x, minind));
                     dxy_acc(acc, dxy_site(x1[u].y, x2[u].y, k1[u].y, k2[u].y, minind));
@@ -327,11 +329,12 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
     stage.flush();
 }
 
+template <int U = 2>
 __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const double *p2, const int32_t *n1,
                                                         const int32_t *n2, uint64_t n, int minind, uint64_t n_l2,
                                                         TreeView tv) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
-    dxy_build_body(p1, p2, n1, n2, n, minind, n_l2, tv, lds_stage);
+    dxy_build_body<U>(p1, p2, n1, n2, n, minind, n_l2, tv, lds_stage);
 }
 
 // BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
@@ -346,9 +349,10 @@ struct DxyHetBuildArgs {
     uint64_t n_l2_dxy, n_items_het;
     TreeView tv_dxy, tv_het[2];
 };
+template <int U = 2>
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
-    if (blockIdx.y == 0) dxy_build_body(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy, lds_stage);
+    if (blockIdx.y == 0) dxy_build_body<U>(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy, lds_stage);
     else het_build_body(f.g[blockIdx.y - 1], f.n, f.n_items_het, f.tv_het[blockIdx.y - 1]);
 }
 
@@ -1034,8 +1038,11 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 // Called once from pgt_open: declares the dynamic-LDS needs of the staged build kernels, so that no
 // attribute call can fall inside a caller's stream capture.
 int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function attributes are per device
-    const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>), reinterpret_cast<const void *>(dxy_build_kernel),
-                            reinterpret_cast<const void *>(dxy_het_build_kernel), reinterpret_cast<const void *>(ext_build_kernel<>)};
+    const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>),
+                            reinterpret_cast<const void *>(fst_build_kernel<kFstStage, 8, true>),
+                            reinterpret_cast<const void *>(dxy_build_kernel<2>), reinterpret_cast<const void *>(dxy_build_kernel<4>),
+                            reinterpret_cast<const void *>(dxy_het_build_kernel<2>), reinterpret_cast<const void *>(dxy_het_build_kernel<4>),
+                            reinterpret_cast<const void *>(ext_build_kernel<>), reinterpret_cast<const void *>(ext_build_kernel<kExtStage, 8, true>)};
     for (const void *k : staged)
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
                               "hipFuncSetAttribute", err))
@@ -1061,8 +1068,18 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
             launched = launch_fst_experiment(s, cols, np, n, tl, tv);
 #endif
             if (!launched) {
-                hipLaunchKernelGGL((fst_build_kernel<>), dim3(build_grid(tl.count[1], kFstBuildBlocks), np), dim3(256),
-                                   kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
+                // Loads in flight per lane: 8 (UNROLL 4) for long inputs; 16 (UNROLL 8) below ~3e8 sites, where the
+                // fixed cost of a launch shows: the last tile of every wave runs latency-bound (16 dependent
+                // batches of 8 loads, ~1 us each), with 16 in flight it is half as long.  Measured fit t = t0 +
+                // bytes/BW: t0 12.0 -> 9.9 us; +1.5 % at 1e8, +1.8 % at 1.25e8, -0.4 % at 1e9 sites
+                // (profiles/r02/size_sweep_variants.md).  The arithmetic order does not depend on it: same bits.
+                const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks), np);
+                if (tl.count[1] * np <= kFstSmallTiles)
+                    hipLaunchKernelGGL((fst_build_kernel<kFstStage, 8, true>), grid, dim3(256), kFstStageBytes, s, cols, n,
+                                       tl.count[1], tv, (uint64_t)0);
+                else
+                    hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv,
+                                       (uint64_t)0);
             }
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
@@ -1120,8 +1137,11 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : hints.max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(dxy_build_kernel, dim3(build_grid(tl.count[1], kFstBuildBlocks)), dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n,
-                           minind, tl.count[1], tv);
+        const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks));
+        if (tl.count[1] <= kFstSmallTiles)  // 16 instead of 8 loads in flight per lane for short inputs (see launch_fst)
+            hipLaunchKernelGGL(dxy_build_kernel<4>, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
+        else
+            hipLaunchKernelGGL(dxy_build_kernel<2>, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(tl, tv, 1, s, err)) return rc;
     }
@@ -1161,7 +1181,10 @@ void launch_ext_build(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t
         default: break;
     }
 #endif
-    launch_ext_variant<kExtStage, 4, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
+    if (n_l2 <= kFstSmallTiles / 2)  // 16 loads in flight per lane for short inputs (see launch_fst); ext tiles are 16384 sites
+        launch_ext_variant<kExtStage, 8, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
+    else
+        launch_ext_variant<kExtStage, 4, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
 }
 
 int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
@@ -1204,7 +1227,11 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         const uint64_t n_items = het_items(n);
         DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], n_items, tvd, {tvh0, tvh1}};
         const uint64_t tiles = td.count[1] > n_items ? td.count[1] : n_items;
-        hipLaunchKernelGGL(dxy_het_build_kernel, dim3(build_grid(tiles, kFstBuildBlocks), 3), dim3(256), kFstStageBytes, s, f);
+        const dim3 grid(build_grid(tiles, kFstBuildBlocks), 3);
+        if (td.count[1] <= kFstSmallTiles)
+            hipLaunchKernelGGL(dxy_het_build_kernel<4>, grid, dim3(256), kFstStageBytes, s, f);
+        else
+            hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kFstStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
         if (int rc = launch_upper<NodeHet>(th, tvh0, 1, s, err, 1, n_items * kHetChunk)) return rc;
