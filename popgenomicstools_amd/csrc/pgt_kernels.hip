@@ -203,7 +203,9 @@ __device__ __forceinline__ void het_count_word(uint32_t w, uint32_t &nonmiss, ui
 // One work item = 8 leaf tiles (8192 sites, 8 KiB): 8 x 16-byte loads in flight per lane, eight
 // level-1 nodes stored by lanes 0-7.  Level 2 is derived from level 1 by tree_up_kernel: with
 // 65536-site level-2 tiles a wave-per-level-2-tile build has too few work items to fill the chip
-// (1526 at 10^8 sites; measured 0.8 TB/s), this form has 8x as many.
+// (1526 at 10^8 sites; measured 0.8 TB/s), this form has 8x as many.  (Round 2, tried and dropped: one
+// WORKGROUP per level-2 tile, 16 leaf tiles per wave, level 2 summed through LDS so that the tree_up launch
+// disappears: 35 us instead of 30 at 10^8 sites, 0.162 instead of 0.158 ms at 10^9 — fewer, fatter items.)
 constexpr int kHetChunk = 8;
 __device__ __forceinline__ void het_build_body(const int8_t *__restrict__ g, uint64_t n, uint64_t n_items,
                                                const TreeView &tv) {

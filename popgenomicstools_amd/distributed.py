@@ -170,14 +170,16 @@ class RowExchange:
         gdst = _global_dst(dist, self.group, self.dst)
         box = [None]
         ok = 1
-        if self.rank == self.dst:
+        if self.ctx is None:  # no library context to create / map the buffer with: every rank reports failure
+            self.peer_error, ok = "no Context given", 0
+        elif self.rank == self.dst:
             try:
                 self.buf, handle = self.ctx.rowbuf_create(self.total)
                 box[0] = handle
             except PgtError as e:
                 self.peer_error, ok = str(e), 0
         dist.broadcast_object_list(box, src=gdst, group=self.group)
-        if self.rank != self.dst:
+        if self.rank != self.dst and ok:
             if box[0] is None:
                 ok = 0
             else:

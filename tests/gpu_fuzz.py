@@ -47,6 +47,8 @@ def main():
         if rng.random() < 0.5:
             W = int(rng.integers(1, max(2, min(n, 5000))))
         S = int(rng.integers(1, W + 1))
+        if rng.random() < 0.3:  # the sliding query's regime (step <= 32 sites)
+            S = int(rng.integers(1, min(W, 32) + 1))
         if n * (W / S) > 4e8:  # keep the oracle's O(N*W/S) affordable
             S = max(S, W // 50 + 1)
         try:
