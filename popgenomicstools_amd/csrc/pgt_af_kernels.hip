@@ -125,9 +125,10 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 }
 
 // ---- BUILD: one wave per level-2 tile (64 leaf tiles of 128 sites) ------------------------------
-// (Tried: 256-site leaf tiles so that the reduce-scatter runs half as often: no gain at 8
-// populations, 53.6 % vs 56.7 % of HBM peak.  The kernel is bound by the 2 x (NP*3 + pairs*2) f64
-// operations per lane and tile and by occupancy — 188 VGPRs, 2 waves per SIMD — not by the exchanges.)
+// (Tried twice: 256-site leaf tiles, which halve the node bytes and the reduce-scatters.  Round 1, value-major
+// tree: 53.6 % vs 56.7 % of the HBM peak at 8 populations.  Round 2, node-major tree and balanced grid: the
+// node stores then cost 4 points instead of 9, but the larger level-2 tiles (1 MiB of reads, 6104 of them at
+// 10^8 sites) lose as much: 65.8-70.8 % vs 74.9 %.  Kept: 128-site leaves.)
 template <int NP, int ABLATE = 0>  // ABLATE (tuning build only, wrong results): 1 no reduce-scatter, 2 no node stores, 3 no accumulate
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
