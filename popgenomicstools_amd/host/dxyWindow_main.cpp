@@ -61,13 +61,24 @@ struct Maf {
     }
 };
 
-static void read_maf(const char *path, const char *which, Maf &m) {
+static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache) {
+    std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(int32_t)}};
+    if (cache.load(m.n, m.runs, cols)) {  // only with PGT_COLUMN_CACHE=<dir>; plain (not gzipped-by-name-only) regular files
+        m.pos.borrow(static_cast<uint32_t *>(cols[0].data));
+        m.freq.borrow(static_cast<double *>(cols[1].data));
+        m.nind.borrow(static_cast<int32_t *>(cols[2].data));
+        return;
+    }
     Text text;
     if (!text.open(path)) die(std::string("Unable to open ") + which + " MAF file: " + path);
     Cursor hdr{text.begin(), text.end()};
     hdr.next_line();  // header (dxyWindow.cpp:284)
     m.n = parse_table(hdr.p, text.end(), m, m.runs,
                       "dxyWindow: cannot parse MAF line (chr pos major minor ref freq nind, freq in [0,1])", path, 2);
+    if (cache.enabled()) {
+        cols[0].data = m.pos.data(); cols[1].data = m.freq.data(); cols[2].data = m.nind.data();
+        cache.store(m.n, m.runs, cols);
+    }
 }
 
 int main(int argc, char **argv) {
@@ -114,9 +125,10 @@ int main(int argc, char **argv) {
     PhaseTimer timer;
     DeviceOpener device;  // HIP start-up runs beside the parse
     Maf m1, m2;
+    ColumnCache c1("dxyWindow maf", argv[argc - 2]), c2("dxyWindow maf", argv[argc - 1]);  // own the mappings the columns may borrow
     {   // the two files are independent: parse them side by side
-        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1); });
-        read_maf(argv[argc - 1], "Pop2", m2);
+        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1, c1); });
+        read_maf(argv[argc - 1], "Pop2", m2, c2);
         t1.join();
     }
     timer.lap("parse");

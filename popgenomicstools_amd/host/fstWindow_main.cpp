@@ -23,8 +23,11 @@ int main(int argc, char **argv) {
         return 0;
     }
     PhaseTimer timer;
-    Text text;
-    if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
+    {   // the reference opens the file before it looks at the other arguments (fstWindow.cpp:45-49)
+        FILE *probe = std::fopen(argv[1], "rb");
+        if (!probe) die(std::string("Unable to open Fst variance components file ") + argv[1]);
+        std::fclose(probe);
+    }
     parse_window_args(argc, argv, W, S);
     DeviceOpener device;  // HIP start-up runs beside the parse
 
@@ -41,8 +44,25 @@ int main(int argc, char **argv) {
         }
     } tab;
     Runs runs;
-    const size_t n = parse_table(text.begin(), text.end(), tab, runs, "fstWindow: cannot parse 'chr pos a b'", argv[1], 1);
-    timer.lap("parse");
+    size_t n = 0;
+    ColumnCache cache("fstWindow", argv[1]);  // only with PGT_COLUMN_CACHE=<dir>
+    std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(double)}};
+    if (cache.load(n, runs, cols)) {
+        tab.pos.borrow(static_cast<uint32_t *>(cols[0].data));
+        tab.a.borrow(static_cast<double *>(cols[1].data));
+        tab.b.borrow(static_cast<double *>(cols[2].data));
+        timer.lap("cache map");
+    } else {
+        Text text;
+        if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
+        n = parse_table(text.begin(), text.end(), tab, runs, "fstWindow: cannot parse 'chr pos a b'", argv[1], 1);
+        timer.lap("parse");
+        if (cache.enabled()) {
+            cols[0].data = tab.pos.data(); cols[1].data = tab.a.data(); cols[2].data = tab.b.data();
+            cache.store(n, runs, cols);
+            timer.lap("cache write");
+        }
+    }
 
     size_t n_win = 0;
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);

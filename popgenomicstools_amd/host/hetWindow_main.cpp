@@ -25,8 +25,11 @@ int main(int argc, char **argv) {
         return 0;
     }
     PhaseTimer timer;
-    Text text;
-    if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
+    {   // the reference opens the file before it looks at the other arguments (hetWindow.cpp:42-46)
+        FILE *probe = std::fopen(argv[1], "rb");
+        if (!probe) die(std::string("Unable to open genotypes file ") + argv[1]);
+        std::fclose(probe);
+    }
     parse_window_args(argc, argv, W, S);
     DeviceOpener device;  // HIP start-up runs beside the parse
 
@@ -46,8 +49,24 @@ int main(int argc, char **argv) {
         }
     } tab;
     Runs runs;
-    const size_t n = parse_table(text.begin(), text.end(), tab, runs, "hetWindow: cannot parse 'chr pos genotype'", argv[1], 1);
-    timer.lap("parse");
+    size_t n = 0;
+    ColumnCache cache("hetWindow", argv[1]);  // only with PGT_COLUMN_CACHE=<dir>
+    std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(int8_t)}};
+    if (cache.load(n, runs, cols)) {
+        tab.pos.borrow(static_cast<uint32_t *>(cols[0].data));
+        tab.g.borrow(static_cast<int8_t *>(cols[1].data));
+        timer.lap("cache map");
+    } else {
+        Text text;
+        if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
+        n = parse_table(text.begin(), text.end(), tab, runs, "hetWindow: cannot parse 'chr pos genotype'", argv[1], 1);
+        timer.lap("parse");
+        if (cache.enabled()) {
+            cols[0].data = tab.pos.data(); cols[1].data = tab.g.data();
+            cache.store(n, runs, cols);
+            timer.lap("cache write");
+        }
+    }
 
     size_t n_win = 0;
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);

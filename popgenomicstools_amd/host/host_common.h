@@ -241,13 +241,15 @@ inline int host_threads() {
 template <class T>
 struct Column {
     std::unique_ptr<T[]> p;
+    T *view = nullptr;  // set when the column lives in a mapped cache file instead of `p`
     size_t n = 0;
-    void alloc(size_t cap) { p.reset(new T[cap ? cap : 1]); }
-    T *data() { return p.get(); }
-    const T *data() const { return p.get(); }
+    void alloc(size_t cap) { p.reset(new T[cap ? cap : 1]); view = nullptr; }
+    void borrow(T *mapped) { p.reset(); view = mapped; }
+    T *data() { return view ? view : p.get(); }
+    const T *data() const { return view ? view : p.get(); }
     size_t size() const { return n; }
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
+    T &operator[](size_t i) { return data()[i]; }
+    const T &operator[](size_t i) const { return data()[i]; }
 };
 
 // Two passes over the text, both parallel over chunks cut at line boundaries:
@@ -316,6 +318,110 @@ size_t parse_table(const char *b, const char *e, Table &tab, Runs &runs, const c
     }
     return n;
 }
+
+// ---- binary column cache ------------------------------------------------------
+// The reference re-parses its text input on every run (fstWindow.cpp:123-146); at 10^8 lines the parse is
+// 0.3 s of this host's 0.4 s.  With PGT_COLUMN_CACHE=<directory> in the environment (the command line stays
+// the reference's) the parsed structure-of-arrays columns and chromosome runs of an input file are written
+// to <directory>/<key>.pgtcols and mapped straight back on later runs; key = hash of (tool tag, resolved
+// path, size, mtime in ns), so an edited or replaced input is simply parsed again.  Plain regular files
+// only (a pipe has no identity to key on).  Layout: "PGTCOLS1", u64 rows, u64 n_runs, u64 n_cols, per run
+// {u64 len, u64 name bytes, name padded to 8}, then per column {u64 bytes, data padded to 64}.
+class ColumnCache {
+  public:
+    struct Col { void *data; size_t elem; };  // in: the parsed column; out: pointer into the mapping
+    ColumnCache(const char *tag, const char *input) {
+        const char *dir = std::getenv("PGT_COLUMN_CACHE");
+        if (!dir || !*dir) return;
+        struct stat st;
+        if (stat(input, &st) != 0 || !S_ISREG(st.st_mode)) return;
+        char real[4096];
+        if (!realpath(input, real)) return;
+        uint64_t h = 1469598103934665603ull;  // FNV-1a
+        auto mix = [&](const void *p, size_t n) {
+            for (size_t i = 0; i < n; ++i) h = (h ^ static_cast<const unsigned char *>(p)[i]) * 1099511628211ull;
+        };
+        const uint64_t size = (uint64_t)st.st_size, mt = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+        mix(tag, std::strlen(tag) + 1); mix(real, std::strlen(real) + 1); mix(&size, 8); mix(&mt, 8);
+        char name[32];
+        std::snprintf(name, sizeof name, "%016llx", (unsigned long long)h);
+        path_ = std::string(dir) + "/" + name + ".pgtcols";
+    }
+    ~ColumnCache() {
+        if (map_) munmap(map_, map_len_);
+    }
+    bool enabled() const { return !path_.empty(); }
+    // maps the cache file; fills rows, runs and the column pointers (cols[i].elem must match)
+    bool load(size_t &rows, Runs &runs, std::vector<Col> &cols) {
+        if (!enabled()) return false;
+        const int fd = ::open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 32) { ::close(fd); return false; }
+        map_len_ = (size_t)st.st_size;
+        map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (map_ == MAP_FAILED) { map_ = nullptr; return false; }
+        const char *b = static_cast<const char *>(map_), *e = b + map_len_, *p = b;
+        auto u64 = [&](uint64_t &v) { if (p + 8 > e) return false; std::memcpy(&v, p, 8); p += 8; return true; };
+        uint64_t n = 0, n_runs = 0, n_cols = 0;
+        if (std::memcmp(p, "PGTCOLS1", 8) != 0) return false;
+        p += 8;
+        if (!u64(n) || !u64(n_runs) || !u64(n_cols) || n_cols != cols.size()) return false;
+        Runs r;
+        for (uint64_t k = 0; k < n_runs; ++k) {
+            uint64_t len = 0, nb = 0;
+            if (!u64(len) || !u64(nb) || p + ((nb + 7) & ~7ull) > e) return false;
+            r.name.emplace_back(p, p + nb);
+            r.len.push_back(len);
+            p += (nb + 7) & ~7ull;
+        }
+        for (auto &c : cols) {
+            uint64_t bytes = 0;
+            if (!u64(bytes) || bytes != n * c.elem) return false;
+            p = b + (((size_t)(p - b) + 63) & ~(size_t)63);
+            if (p + bytes > e) return false;
+            c.data = const_cast<char *>(p);
+            p += bytes;
+        }
+        madvise(map_, map_len_, MADV_SEQUENTIAL | MADV_WILLNEED);
+        rows = (size_t)n;
+        runs = std::move(r);
+        return true;
+    }
+    // written to a temporary name and renamed, so that a concurrent reader never sees half a file;
+    // failures (read-only directory, disk full) are silent: the cache is an optimisation
+    void store(size_t rows, const Runs &runs, const std::vector<Col> &cols) const {
+        if (!enabled()) return;
+        const std::string tmp = path_ + "." + std::to_string((long)getpid()) + ".tmp";
+        FILE *f = std::fopen(tmp.c_str(), "wb");
+        if (!f) return;
+        bool ok = true;
+        size_t at = 0;
+        auto put = [&](const void *p, size_t n) { ok = ok && std::fwrite(p, 1, n, f) == n; at += n; };
+        auto u64 = [&](uint64_t v) { put(&v, 8); };
+        static const char zeros[64] = {0};
+        put("PGTCOLS1", 8);
+        u64(rows); u64(runs.name.size()); u64(cols.size());
+        for (size_t k = 0; k < runs.name.size(); ++k) {
+            u64(runs.len[k]); u64(runs.name[k].size());
+            put(runs.name[k].data(), runs.name[k].size());
+            put(zeros, (8 - runs.name[k].size() % 8) % 8);
+        }
+        for (const auto &c : cols) {
+            u64((uint64_t)rows * c.elem);
+            put(zeros, (64 - at % 64) % 64);
+            put(c.data, rows * c.elem);
+        }
+        ok = std::fclose(f) == 0 && ok;
+        if (!ok || std::rename(tmp.c_str(), path_.c_str()) != 0) std::remove(tmp.c_str());
+    }
+
+  private:
+    std::string path_;
+    void *map_ = nullptr;
+    size_t map_len_ = 0;
+};
 
 // ---- TSV writer -----------------------------------------------------------------------------
 // With -winsize 1 -stepsize 1 style runs (dxyWindow.cpp:47) the number of rows approaches the

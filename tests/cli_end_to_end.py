@@ -51,6 +51,18 @@ def main():
             same, t_ref_s, sp = "n/a", "n/a", "n/a"
         phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
         print(f"| {tool} | {t_ref_s} | {t_new:.2f} | {sp} | {len(r_new.stdout.splitlines())} | {same} | {phases} |")
+        # the same run with the binary column cache (PGT_COLUMN_CACHE): first run writes it, second maps it
+        cdir = os.path.join(d, "cache_" + tool)
+        os.mkdir(cdir)
+        cenv = dict(env, PGT_COLUMN_CACHE=cdir)
+        t_w, r_w = wall([os.path.join(BIN, tool), path, "50000", "10000"], cenv)
+        t_c, r_c = wall([os.path.join(BIN, tool), path, "50000", "10000"], cenv)
+        phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_c.stderr.decode().splitlines() if "pgt-host" in ln)
+        print(f"| {tool}, PGT_COLUMN_CACHE (2nd run; the 1st, writing the cache, took {t_w:.2f} s) | {t_ref_s} | {t_c:.2f} | "
+              f"{(t_ref / t_c if ref else 0):.1f}x | {len(r_c.stdout.splitlines())} | {r_c.stdout == r_new.stdout} | {phases} |")
+        for fn in os.listdir(cdir):
+            os.unlink(os.path.join(cdir, fn))
+        os.rmdir(cdir)
     # dxyWindow: the reference source needs Boost (absent here), so the CPU side of this row is the oracle's
     # text front end — our restatement of dxyWindow.cpp's streaming loop ("port"), single-threaded.
     nd = min(n, 20_000_000)  # two MAF files of ~35 B per line: bounded so that the scratch disk is enough

@@ -271,3 +271,68 @@ def test_cli_input_format_edge_cases(hosts, tmp_path):
     with gzip.open(gz, "wt") as fh:
         fh.write(plain)
     assert run([hosts["fstWindow"], str(gz), "4", "2"]).stdout == ref.stdout
+
+
+# ---- binary column cache (PGT_COLUMN_CACHE) ----------------------------------------------
+def test_column_cache_is_written_and_tolerates_garbage(hosts, tmp_path):
+    """CPU (an input without windows never touches the GPU): the cache file appears on the first run, is
+    accepted on the second, and a truncated / foreign file under its name is ignored, not trusted."""
+    f = tmp_path / "short.txt"
+    f.write_text("c\t1\t0.1\t0.2\nc\t2\t0.1\t0.2\nc\t3\t0.1\t0.2\n")
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, PGT_COLUMN_CACHE=str(cache), PGT_HOST_TIMING="1")
+    r = run([hosts["fstWindow"], str(f), "5", "2"], env=env)
+    assert r.returncode == 0 and r.stdout == "" and "parse" in r.stderr and "cache write" in r.stderr
+    files = list(cache.glob("*.pgtcols"))
+    assert len(files) == 1 and files[0].read_bytes()[:8] == b"PGTCOLS1"
+    r = run([hosts["fstWindow"], str(f), "5", "2"], env=env)
+    assert r.returncode == 0 and "cache map" in r.stderr and "parse" not in r.stderr
+    files[0].write_bytes(b"PGTCOLS1" + b"\xff" * 40)
+    r = run([hosts["fstWindow"], str(f), "5", "2"], env=env)
+    assert r.returncode == 0 and "parse" in r.stderr  # garbage is not trusted: parsed again (and rewritten)
+    # a directory that does not exist only disables the cache
+    r = run([hosts["fstWindow"], str(f), "5", "2"], env=dict(env, PGT_COLUMN_CACHE=str(tmp_path / "nope")))
+    assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_column_cache_gives_the_same_tsv(hosts, tmp_path):
+    """fstWindow / hetWindow / dxyWindow (one MAF gzipped): without the cache, writing it, and mapping it back
+    print the same bytes; an edited input gets a new key and is parsed again."""
+    rng = np.random.default_rng(12)
+    n = 30_000
+    import synth
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    ffst, fhet = tmp_path / "fst.txt", tmp_path / "het.txt"
+    ffst.write_text("".join(f"chr{c}\t{p}\t{x:.6f}\t{y:.6f}\n" for c, p, x, y in zip(chr_ids, pos, a, b)))
+    fhet.write_text("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids, pos, g)))
+    m1, m2 = tmp_path / "p1.mafs.gz", tmp_path / "p2.mafs"
+    hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd\n"
+    with gzip.open(m1, "wt") as fh:
+        fh.write(hdr + "".join(f"chr{c}\t{p}\tA\tC\tA\t{x:.6f}\t{k}\n" for c, p, x, k in zip(chr_ids, pos, p1, n1)))
+    m2.write_text(hdr + "".join(f"chr{c}\t{p}\tA\tC\tA\t{x:.6f}\t{k}\n" for c, p, x, k in zip(chr_ids, pos, p2, n2)))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, PGT_COLUMN_CACHE=str(cache))
+    cmds = [[hosts["fstWindow"], str(ffst), "500", "100"], [hosts["hetWindow"], str(fhet), "500", "100"],
+            [hosts["dxyWindow"], "-winsize", "500", "-stepsize", "100", "-minind", "5", "-fixedsite", "1", str(m1), str(m2)]]
+    outputs = []
+    for cmd in cmds:
+        plain = run(cmd)
+        outputs.append(plain.stdout)
+        first = run(cmd, env=env)
+        second = run(cmd, env=env)
+        assert plain.returncode == first.returncode == second.returncode == 0, plain.stderr + first.stderr + second.stderr
+        assert plain.stdout and plain.stdout == first.stdout == second.stdout
+        assert plain.stderr == first.stderr == second.stderr  # dxy's genome-wide line
+    assert len(list(cache.glob("*.pgtcols"))) == 4  # fst, het, two MAF files
+    # edited input: same path, new content -> new key, new answer
+    ffst.write_text("".join(f"chr{c}\t{p}\t{y:.6f}\t{x + 0.5:.6f}\n" for c, p, x, y in zip(chr_ids, pos, a, b)))
+    os.utime(ffst, ns=(1, 1))
+    changed = run(cmds[0], env=env)
+    assert changed.returncode == 0 and changed.stdout == run(cmds[0]).stdout and changed.stdout != outputs[0]
+    assert len(list(cache.glob("*.pgtcols"))) == 5
