@@ -771,8 +771,9 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
 // shifts W-S (fstWindow.cpp:95-99).  Each of the three pieces is computed in an order that depends on
 // the window alone (whole-tile scans in a fixed lane order; the interior by range_partial), never on
 // which other windows share the wave: rows are bitwise independent of the grouping, hence of the
-// number of GPUs a table is sharded over.  Windows that do not fit the pattern (shorter than two
-// tiles, or starting/ending outside the group's two tiles) are answered one by one as in query_body.
+// number of GPUs a table is sharded over.  Windows that start or end outside the group's two tiles take
+// the same three pieces from scans of their OWN tiles; windows too short to be split (A > B) and empty
+// windows take the plain range query of query_body — one by one, after the group's common work.
 // ------------------------------------------------------------------------------------------
 constexpr int kSlideTile = 128;
 template <class Node>
