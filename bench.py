@@ -20,6 +20,10 @@ time.  After the timed region rank 0 rebuilds the whole genome, runs the single-
 the assembled multi-GPU table to be bitwise equal ("rows_check"); the table's SHA-256 ("rows_sha256")
 is the same for every N.  --scaling weak instead gives every rank --sites sites (genome = N x --sites).
 
+`--workload pairs --sites 1e8 --chroms 20` runs BASELINE configs[4] the same way: all 28 pairs of 8 populations
+batched in one launch per step over one window table, site ranges sharded over the N GPUs, the 28 x windows
+rows of every rank delivered to rank 0 and checked bit for bit against the single-GPU call.
+
 The default N=1 run also times BASELINE configs 2, 3 and 5 in their one-GPU form at 10^8 sites
 ("extra"; --headline-only skips them, e.g. under rocprofv3 --stats) and the reference CPU path on a
 bounded sample ("cpu_baseline").  Prints ONE JSON line on rank 0.
@@ -204,7 +208,13 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
+    ap.add_argument("--workload", choices=["fst", "pairs"], default="fst",
+                    help="fst = the headline 2-population scan (default); pairs = BASELINE configs[4]: all --pairs population pairs "
+                         "batched over one window table (use --sites 1e8 --chroms 20), sharded by site range like the headline")
+    ap.add_argument("--pairs", type=int, default=28, help="population pairs of --workload pairs (8 populations = 28)")
     args = ap.parse_args()
+    pairs_mode = args.workload == "pairs"
+    n_tables = args.pairs if pairs_mode else 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -237,20 +247,37 @@ def main():
     local["lo"] -= site_lo
     local["hi"] -= site_lo
     n = site_hi - site_lo  # sites resident on this GPU (own block + halo)
-    pos, a, b = genome.fst_columns_t(site_lo, site_hi, dev)
+
+    def load_columns(lo_, hi_):
+        """-> (pos, [a per pair], [b per pair]) of sites [lo_, hi_) on this GPU"""
+        if not pairs_mode:
+            p_, a_, b_ = genome.fst_columns_t(lo_, hi_, dev)
+            return p_, [a_], [b_]
+        cols = [genome.pair_columns_t(k, lo_, hi_, dev) for k in range(n_tables)]
+        return genome.pos_t(lo_, hi_, dev), [c[0] for c in cols], [c[1] for c in cols]
+
+    def scan(cols, wtab, out, tree_):
+        if pairs_mode:
+            return ctx.fst_reduce_pairs_dev(cols[0], cols[1], cols[2], wtab, out=out, tree=tree_)
+        return ctx.fst_reduce_dev(cols[0], cols[1][0], cols[2][0], wtab, out=out, tree=tree_)
+
+    mycols = load_columns(site_lo, site_hi)
+    pos, a, b = mycols[0], mycols[1][0], mycols[2][0]
     win_d = windows_to_device(local, dev)
     ctx = pgt.Context(dev_index)
     ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
+    want_extra = world == 1 and not args.headline_only and not pairs_mode
     tree_bytes = max(ctx.tree_bytes(PGT_STAT_FST, n), 28 * ctx.tree_bytes(PGT_STAT_FST, 100_000_000),
                      ctx.tree_bytes(PGT_STAT_DXY, 100_000_000) + 2 * ctx.tree_bytes(PGT_STAT_HET, 100_000_000)) \
-        if (world == 1 and not args.headline_only) else ctx.tree_bytes(PGT_STAT_FST, n)
+        if want_extra else n_tables * ctx.tree_bytes(PGT_STAT_FST, n)
     tree = torch.empty(tree_bytes, dtype=torch.uint8, device=dev)
-    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64)
-    ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=args.exchange, coll_device=coll_dev)
+    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64) * n_tables  # rows per rank and step
+    ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=args.exchange, coll_device=coll_dev,
+                     tables=n_tables)
 
     def step():
         out = ex.begin()
-        ctx.fst_reduce_dev(pos, a, b, win_d, out=out, tree=tree)
+        scan(mycols, win_d, out, tree)
         ex.end()
 
     def fence():
@@ -284,9 +311,10 @@ def main():
     def single_gpu_table():
         """rank 0: the whole genome on this one GPU through the same entry point (outside any timed region)."""
         if "t" not in single:
-            fp, fa, fb = genome.fst_columns_t(0, n_total, dev)
-            ftree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n_total), dtype=torch.uint8, device=dev)
-            fout, _ = ctx.fst_reduce_dev(fp, fa, fb, windows_to_device(win, dev), tree=ftree)
+            fcols = load_columns(0, n_total)
+            ftree = torch.empty(n_tables * ctx.tree_bytes(PGT_STAT_FST, n_total), dtype=torch.uint8, device=dev)
+            fout = torch.empty(n_tables * win.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            scan(fcols, windows_to_device(win, dev), fout, ftree)
             single["t"] = fout.cpu().numpy().tobytes()
         return single["t"]
 
@@ -303,7 +331,8 @@ def main():
                 print("bench.py: peer-store table differs from the single-GPU table; re-running with the RCCL gather",
                       file=sys.stderr, flush=True)
             ex.close()
-            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode="gather", coll_device=coll_dev)
+            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode="gather", coll_device=coll_dev,
+                             tables=n_tables)
             dt = timed_region()
             table = ex.finish()
             if rank == 0:
@@ -318,32 +347,32 @@ def main():
     if rank == 0:
         sha = hashlib.sha256(table.tobytes()).hexdigest()
         rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)
-        assert rows.size == win.size
+        assert rows.size == n_tables * win.size  # table-major: pair 0's rows come first
 
     # --- roofline of the dominant kernel: HIP events on the launch stream, around the build pass only
     scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
     ctx.set_profiling(True)
     build_ms, query_ms = [], []
     for _ in range(max(5, min(args.steps, 20))):
-        ctx.fst_reduce_dev(pos, a, b, win_d, out=scratch, tree=tree)
+        scan(mycols, win_d, scratch, tree)
         bm, qm = ctx.last_kernel_ms()
         build_ms.append(bm)
         query_ms.append(qm)
     ctx.set_profiling(False)
     build_avg = float(np.mean(build_ms))
-    achieved = BYTES_PER_SITE * n / (build_avg * 1e-3) / 1e9  # GB/s
+    achieved = BYTES_PER_SITE * n_tables * n / (build_avg * 1e-3) / 1e9  # GB/s
 
     # --- sanity: a sample of windows against float64 sums taken by torch (independent path)
     if rank == 0:
         mine = np.arange(int(sh["win_begin"]), int(sh["win_end"]))
         for i in mine[np.linspace(0, mine.size - 1, 7).astype(int)]:
             lo, hi = int(win["lo"][i]) - site_lo, int(win["hi"][i]) - site_lo
-            ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())
+            ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())  # pair 0 = the first table
             assert abs(rows["fst"][i] - ref) <= 1e-9 * abs(ref) + 1e-12, (i, rows["fst"][i], ref)
             assert rows["n"][i] == hi - lo and rows["start"][i] == (int(pos[lo]) & 0xFFFFFFFF)
 
     extra, cpu = {}, None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not pairs_mode:
         if not args.headline_only:
             extra = extra_configs(ctx, dev, W, S, tree)
             ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
@@ -353,7 +382,8 @@ def main():
     if rank == 0:
         per_gpu = [int(s["site_hi"] - s["site_lo"]) for s in shards]
         line = {
-            "metric": "genomic sites/sec for 2-pop FST window scan",
+            "metric": ("genomic sites/sec for 2-pop FST window scan" if not pairs_mode else
+                       f"genomic sites/sec for the all-pairs FST window scan ({n_tables} population pairs per site)"),
             "value": float(n_total) * args.steps / dt,
             "unit": "sites/s",
             "n_gpus": world,
@@ -365,13 +395,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"fstWindow 2 pops x {n_total:.0e} sites total in {genome.run_len.size} chromosomes"
+            "config": {"workload": (f"fstWindow 2 pops x {n_total:.0e} sites total" if not pairs_mode else
+                                    f"fstWindow all {n_tables} pairs of 8 populations x {n_total:.0e} sites total, one batched call per step,")
+                                   + f" in {genome.run_len.size} chromosomes"
                                    + (f" sharded x{world} by window blocks (pgt_plan_shards)" if world > 1 else "")
                                    + f", window {W} sites / step {S} sites, {win.size} windows, columns resident in HBM"
                                    + (f", rows to rank 0 by {'peer stores over xGMI' if ex.mode == 'peer' else 'async RCCL gather'}"
                                       if world > 1 else ""),
-                       "baseline_config": "BASELINE configs[3] (10^9-site fstWindow scan sharded over the GPUs; at N=1 the same genome "
-                                          "on one GPU: the size north_star's roofline target is quoted on); configs[1], [2], [4] in `extra`",
+                       "baseline_config": ("BASELINE configs[3] (10^9-site fstWindow scan sharded over the GPUs; at N=1 the same genome "
+                                           "on one GPU: the size north_star's roofline target is quoted on); configs[1], [2], [4] in `extra`"
+                                           if not pairs_mode else
+                                           "BASELINE configs[4]: fstWindow all-pairs of 8 populations x 10^8 sites, pairs batched in one launch, "
+                                           "site ranges sharded over the GPUs"),
                        "sites_total": n_total, "sites_resident_per_gpu": per_gpu, "winsize": W, "stepsize": S,
                        "windows": int(win.size), "seed": SEED, "row_exchange": ex.mode,
                        "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
@@ -382,7 +417,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "traffic_source": "profiles/r02/pmc_counters.csv (separate rocprofv3 --pmc passes; not measured by this run)",
                          "kernel_ms": build_avg, "query_kernel_ms": float(np.mean(query_ms)),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SITE * n, "sites_per_launch": n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SITE * n_tables * n, "sites_per_launch": n},
             "cpu_baseline": cpu,
             "extra": extra,
         }
