@@ -1,0 +1,38 @@
+"""GPU: bench.py itself, small — the single-GPU line and the N > 1 path (two ranks sharing GPU 0 over gloo,
+the rehearsal knobs of bench.py), both row transports: the sharded table must be the single-GPU table."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--sites", "3e6", "--chroms", "5", "--steps", "3", "--warmup", "1", "--headline-only", "--no-cpu"]
+
+
+def _line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", [[], ["--workload", "pairs", "--pairs", "3"]])
+def test_bench_single_and_two_rank_tables_agree(workload):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + workload, capture_output=True,
+                               text=True, env=env, timeout=400))
+    assert one["n_gpus"] == 1 and one["unit"] == "sites/s" and one["value"] > 0 and 0 < one["roofline"]["frac"] < 1
+    assert one["roofline"]["traffic"] is None and one["config"]["row_exchange"] == "local" and one["rows_check"] is None
+    for mode, port in (("peer", "29561"), ("gather", "29562")):
+        env2 = dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PGT_BENCH_BACKEND="gloo", PGT_BENCH_SHARE_GPU="1")
+        two = _line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                    "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                                    "--gpus", "2", "--exchange", mode] + SMALL + workload,
+                                   capture_output=True, text=True, env=env2, timeout=400))
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["row_exchange"] == mode
+        assert two["rows_check"].startswith("bitwise equal")
+        assert two["rows_sha256"] == one["rows_sha256"]
+        assert sum(two["config"]["sites_resident_per_gpu"]) < 1.2 * one["config"]["sites_total"]
