@@ -1,0 +1,139 @@
+// CPU check of the hosts' own ingest code (popgenomicstools_amd/host/host_common.h), built with ASan + UBSan
+// by tests/test_sanitizers.py:
+//   1. to_f64 against strtod (the conversion behind the reference's operator>>) on random and hand-picked
+//      tokens: whatever it accepts has strtod's bits;
+//   2. parse_table on a generated table, single- and multi-chunk;
+//   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused.
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "host_common.h"
+
+using namespace pgthost;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
+
+static void check_token(const std::string &s) {
+    double a = 123.0;
+    const Tok t{s.data(), s.data() + s.size()};
+    const bool fa = to_f64(t, a);
+    if (fa) {
+        const char *start = s.c_str() + (s[0] == '+' ? 1 : 0);
+        char *end = nullptr;
+        const double c = std::strtod(start, &end);
+        if (*end == 0 && std::memcmp(&a, &c, 8) != 0) { std::fprintf(stderr, "strtod differs on '%s'\n", s.c_str()); ++fails; }
+    }
+}
+
+int main(int argc, char **argv) {
+    const long n = argc > 1 ? std::atol(argv[1]) : 300000;
+    std::mt19937_64 rng(argc > 2 ? std::atoll(argv[2]) : 7);
+    for (const char *s : {"0", "-0", "+0", "0.0", "-0.000000", "1", "1.", ".5", "-.5", "+.5", "1e5", "1E5", "1e+5", "1e-5", "1e", "1e+",
+                          "e5", ".", "-", "+", "+-1", "-+1", "++1", "1.5e-05", "0.123456", "-0.000012", "123456789", "0.300000",
+                          "999999999999999", "9999999999999999", "0.1234567890123456789", "1e22", "1e23", "1e-22", "1e-23", "123e20",
+                          "1e400", "1e-400", "nan", "inf", "-inf", "NaN", "0x10", "1,5", "1.5x", " 1", "1 ", "00012.5000", "1e0005",
+                          "4.9e-324", "2.2250738585072014e-308", "17976931348623157e292", "0.000000000000000000001"})
+        check_token(s);
+    for (long i = 0; i < n; ++i) {
+        std::string s;
+        const int kind = (int)(rng() % 6);
+        if (rng() % 7 == 0) s += rng() % 2 ? "-" : "+";
+        const int nint = (int)(rng() % (kind == 0 ? 3 : 12)), nfrac = (int)(rng() % (kind == 1 ? 20 : 8));
+        for (int k = 0; k < nint; ++k) s += (char)('0' + rng() % 10);
+        if (nfrac || rng() % 5 == 0) {
+            s += '.';
+            for (int k = 0; k < nfrac; ++k) s += (char)('0' + rng() % 10);
+        }
+        if (kind >= 4) {
+            s += rng() % 2 ? 'e' : 'E';
+            if (rng() % 2) s += rng() % 2 ? '-' : '+';
+            s += std::to_string(rng() % (kind == 4 ? 30 : 330));
+        }
+        if (rng() % 50 == 0) s += (char)("xe.-+ "[rng() % 6]);
+        check_token(s);
+    }
+
+    // ---- parse_table + ColumnCache round trip --------------------------------------------------
+    struct Table {
+        Column<uint32_t> pos;
+        Column<double> a, b;
+        void alloc(size_t rows) { pos.alloc(rows); a.alloc(rows); b.alloc(rows); }
+        bool parse_line(Cursor &c, size_t i, Runs &runs) {
+            const Tok chr = c.token();
+            if (!to_u32(c.token(), pos[i]) || !to_f64(c.token(), a[i]) || !to_f64(c.token(), b[i])) return false;
+            runs.add(chr.first, chr.second);
+            return true;
+        }
+    };
+    const size_t rows = 200000;
+    std::string text;
+    std::vector<double> va(rows), vb(rows);
+    for (size_t i = 0; i < rows; ++i) {
+        char line[96];
+        va[i] = (double)(int64_t)(rng() % 2000000 - 1000000) / 1e6;
+        vb[i] = (double)(rng() % 300001) / 1e6;
+        text.append(line, (size_t)std::snprintf(line, sizeof line, "chr%zu\t%zu\t%.6f\t%.6f\n", i * 7 / rows + 1, i % 50000 + 1, va[i], vb[i]));
+    }
+    for (int threads : {1, 5}) {
+        setenv("PGT_HOST_THREADS", std::to_string(threads).c_str(), 1);
+        std::string padded = text;
+        if (threads > 1) padded.append(std::string((1u << 20) + 7, ' '));  // > 1 MiB so that the parallel path is taken
+        Table tab;
+        Runs runs;
+        const size_t got = parse_table(padded.data(), padded.data() + text.size(), tab, runs, "check", "mem", 1);
+        CHECK(got == rows && runs.name.size() == 7);
+        for (size_t i = 0; i < rows && got == rows; i += 997) CHECK(tab.a[i] == std::strtod(std::to_string(va[i]).c_str(), nullptr) && tab.b[i] == vb[i]);
+        if (threads == 1) {
+            // cache round trip on this table
+            const std::string dir = argc > 3 ? argv[3] : "/tmp";
+            setenv("PGT_COLUMN_CACHE", dir.c_str(), 1);
+            const std::string input = dir + "/host_parse_check_input.txt";
+            FILE *f = std::fopen(input.c_str(), "wb");
+            std::fwrite(text.data(), 1, text.size(), f);
+            std::fclose(f);
+            std::vector<ColumnCache::Col> cols = {{tab.pos.data(), 4}, {tab.a.data(), 8}, {tab.b.data(), 8}};
+            {
+                ColumnCache c("check", input.c_str());
+                CHECK(c.enabled());
+                size_t n0 = 0;
+                Runs r0;
+                std::vector<ColumnCache::Col> probe = {{nullptr, 4}, {nullptr, 8}, {nullptr, 8}};
+                CHECK(!c.load(n0, r0, probe));  // nothing there yet
+                c.store(rows, runs, cols);
+            }
+            {
+                ColumnCache c("check", input.c_str());
+                size_t n1 = 0;
+                Runs r1;
+                std::vector<ColumnCache::Col> back = {{nullptr, 4}, {nullptr, 8}, {nullptr, 8}};
+                CHECK(c.load(n1, r1, back) && n1 == rows && r1.name == runs.name && r1.len == runs.len);
+                if (n1 == rows) {
+                    CHECK(std::memcmp(back[0].data, tab.pos.data(), rows * 4) == 0);
+                    CHECK(std::memcmp(back[1].data, tab.a.data(), rows * 8) == 0);
+                    CHECK(std::memcmp(back[2].data, tab.b.data(), rows * 8) == 0);
+                    CHECK((reinterpret_cast<uintptr_t>(back[1].data) & 63) == 0);
+                }
+                std::vector<ColumnCache::Col> wrong = {{nullptr, 4}, {nullptr, 8}};  // another tool's column set
+                ColumnCache c2("check", input.c_str());
+                CHECK(!c2.load(n1, r1, wrong));
+                std::vector<ColumnCache::Col> wrong2 = {{nullptr, 8}, {nullptr, 8}, {nullptr, 8}};  // element size mismatch
+                ColumnCache c3("check", input.c_str());
+                CHECK(!c3.load(n1, r1, wrong2));
+            }
+            ColumnCache other("another tool", input.c_str());  // the tag is part of the key
+            size_t n2 = 0;
+            Runs r2;
+            std::vector<ColumnCache::Col> b2 = {{nullptr, 4}, {nullptr, 8}, {nullptr, 8}};
+            CHECK(!other.load(n2, r2, b2));
+            std::remove(input.c_str());
+        }
+    }
+    std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);
+    return fails ? 1 : 0;
+}
