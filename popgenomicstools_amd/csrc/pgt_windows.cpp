@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgt_internal.h"
@@ -24,65 +25,92 @@ namespace {
 
 thread_local std::string g_error;
 
-struct Emitter {
-    pgt_win *out;
-    size_t cap;
-    size_t count = 0;
-    void push(uint64_t lo, uint64_t hi, uint32_t label) {
-        if (out && count < cap) {
-            pgt_win w;
-            w.lo = lo;
-            w.hi = hi;
-            w.label_run = label;
-            w.flags = 0;
-            w.start = w.end = 0;
-            out[count] = w;
-        }
-        ++count;
-    }
-};
-
 // Entry-stream windows shared by both modes.  `entries[r]` is the number of buffer entries run r
 // pushes (sites, or bp slots).  bp_rules selects dxyWindow's slot-mode end-of-run rule
 // (dxyWindow.cpp:353-355: flush only if fill > W-S, and a run that does not flush leaks its
 // entries into the next one) instead of the site-mode rule (fstWindow.cpp:132-134: flush
-// whenever fill > 0).  Emitted ranges are in ENTRY coordinates.
-template <class Emit>
-void entry_windows(const uint64_t *entries, size_t n_runs, uint32_t W, uint32_t S, bool bp_rules, Emit &&emit) {
-    uint64_t g = 0;   // entries pushed before this run
-    uint64_t n0 = 0;  // buffer fill carried into this run
+// whenever fill > 0).  Ranges are in ENTRY coordinates.
+//
+// Two phases, so that neither counting nor filling walks the windows one after the other:
+//   plan_entry_windows   O(#runs): per run the index of its first window, the number K of full
+//                        windows (an arithmetic progression: hi_k = hi0 + k*S) and its end-of-run window;
+//   for_each_window      every window by index, in parallel chunks once there are many (the
+//                        `-stepsize 1` regime: as many windows as sites).
+struct RunPlan {
+    uint64_t out0 = 0;  // index of the run's first window in the table
+    uint64_t K = 0;     // full windows [hi0 + k*S - W, hi0 + k*S), k < K
+    uint64_t hi0 = 0;
+    bool tail = false;  // one more window [tail_lo, tail_hi) at the end of the run
+    uint64_t tail_lo = 0, tail_hi = 0;
+};
+
+uint64_t plan_entry_windows(const uint64_t *entries, size_t n_runs, uint32_t W, uint32_t S, bool bp_rules,
+                            std::vector<RunPlan> &plan) {
+    plan.assign(n_runs, RunPlan{});
+    uint64_t g = 0;    // entries pushed before this run
+    uint64_t n0 = 0;   // buffer fill carried into this run
+    uint64_t out = 0;  // windows emitted so far
     for (size_t r = 0; r < n_runs; ++r) {
+        RunPlan &p = plan[r];
+        p.out0 = out;
         const uint64_t L = entries[r];
-        uint64_t K = 0;
         if (L >= 1 && L - 1 >= (uint64_t)W - n0) {
-            K = (L - 1 - ((uint64_t)W - n0)) / S + 1;
-            for (uint64_t k = 0; k < K; ++k) {
-                const uint64_t hi = g + ((uint64_t)W - n0) + k * S;
-                emit(hi - W, hi, (uint32_t)r);
-            }
+            p.K = (L - 1 - ((uint64_t)W - n0)) / S + 1;
+            p.hi0 = g + ((uint64_t)W - n0);
         }
-        const uint64_t n_end = n0 + L - K * S;
+        const uint64_t n_end = n0 + L - p.K * S;
         g += L;
         const bool last = r + 1 == n_runs;
+        auto tail = [&] { p.tail = true; p.tail_lo = g - n_end; p.tail_hi = g; };
         if (last) {  // fstWindow.cpp:150-152 / dxyWindow.cpp:424-426
-            if (n_end > (uint64_t)(W - S) && n_end <= W) emit(g - n_end, g, (uint32_t)r);
+            if (n_end > (uint64_t)(W - S) && n_end <= W) tail();
             n0 = 0;
         } else if (bp_rules) {  // dxyWindow.cpp:353-355
             if (n_end > (uint64_t)(W - S)) {
-                emit(g - n_end, g, (uint32_t)r);
+                tail();
                 n0 = n_end == W ? W - S : 0;
             } else {
                 n0 = n_end;  // Q3: neither printed nor reset
             }
         } else {  // fstWindow.cpp:132-134 with calcWindow's carry rule :92-103
             if (n_end > 0) {
-                emit(g - n_end, g, (uint32_t)r);
+                tail();
                 n0 = n_end == W ? W - S : 0;
             } else {
                 n0 = 0;
             }
         }
+        out += p.K + (p.tail ? 1 : 0);
     }
+    return out;
+}
+
+// fn(index, lo, hi, label_run) for the windows [0, limit) of the plan; fn must be safe to call concurrently
+// for different indices.
+template <class Fn>
+void for_each_window(const std::vector<RunPlan> &plan, uint64_t limit, uint32_t W, uint32_t S, Fn &&fn) {
+    auto range = [&](uint64_t i0, uint64_t i1) {
+        // first run whose windows reach index i0
+        size_t r = (size_t)(std::upper_bound(plan.begin(), plan.end(), i0,
+                                             [](uint64_t i, const RunPlan &p) { return i < p.out0; }) - plan.begin());
+        r = r ? r - 1 : 0;
+        for (; r < plan.size() && plan[r].out0 < i1; ++r) {
+            const RunPlan &p = plan[r];
+            const uint64_t k0 = i0 > p.out0 ? i0 - p.out0 : 0;
+            const uint64_t k1 = std::min<uint64_t>(p.K, i1 - p.out0);
+            for (uint64_t k = k0; k < k1; ++k) fn(p.out0 + k, p.hi0 + k * S - W, p.hi0 + k * S, (uint32_t)r);
+            if (p.tail && p.out0 + p.K >= i0 && p.out0 + p.K < i1) fn(p.out0 + p.K, p.tail_lo, p.tail_hi, (uint32_t)r);
+        }
+    };
+    unsigned T = std::min(std::thread::hardware_concurrency(), 32u);
+    if (limit < (1u << 20) || T < 2) {
+        range(0, limit);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back(range, limit / T * t, t + 1 == T ? limit : limit / T * (t + 1));
+    for (auto &x : th) x.join();
 }
 
 int fail(int code, const std::string &msg) {
@@ -106,11 +134,20 @@ extern "C" int pgt_build_windows_sites(const uint64_t *run_len, size_t n_runs, u
     if (W < 1 || S < 1 || S > W) return fail(PGT_EARG, "window size and step must satisfy 1 <= step <= window");
     for (size_t r = 0; r < n_runs; ++r)
         if (run_len[r] == 0) return fail(PGT_EARG, "pgt_build_windows_sites: empty chromosome run");
-    Emitter em{out, cap};
-    entry_windows(run_len, n_runs, W, S, false,
-                  [&](uint64_t lo, uint64_t hi, uint32_t label) { em.push(lo, hi, label); });
-    *n_out = em.count;
-    if (out && em.count > cap) return fail(PGT_ECAP, "pgt_build_windows_sites: output capacity too small");
+    std::vector<RunPlan> plan;
+    const uint64_t count = plan_entry_windows(run_len, n_runs, W, S, false, plan);
+    *n_out = (size_t)count;
+    if (out)
+        for_each_window(plan, std::min<uint64_t>(count, cap), W, S, [&](uint64_t i, uint64_t lo, uint64_t hi, uint32_t label) {
+            pgt_win w;
+            w.lo = lo;
+            w.hi = hi;
+            w.label_run = label;
+            w.flags = 0;
+            w.start = w.end = 0;
+            out[i] = w;
+        });
+    if (out && count > cap) return fail(PGT_ECAP, "pgt_build_windows_sites: output capacity too small");
     return PGT_OK;
 }
 
@@ -149,9 +186,11 @@ extern "C" int pgt_build_windows_bp(const uint32_t *pos, const uint64_t *run_len
         return site_base[r] + (uint64_t)(std::lower_bound(p, p + run_len[r], bp) - p);
     };
 
-    Emitter em{out, cap};
-    entry_windows(slots.data(), n_runs, W, S, true, [&](uint64_t Glo, uint64_t Ghi, uint32_t label) {
-        if (out && em.count < cap) {
+    std::vector<RunPlan> plan;
+    const uint64_t count = plan_entry_windows(slots.data(), n_runs, W, S, true, plan);
+    *n_out = (size_t)count;
+    if (out)
+        for_each_window(plan, std::min<uint64_t>(count, cap), W, S, [&](uint64_t i, uint64_t Glo, uint64_t Ghi, uint32_t label) {
             pgt_win w;
             w.lo = first_site_at_or_after(Glo);
             w.hi = first_site_at_or_after(Ghi);
@@ -160,12 +199,9 @@ extern "C" int pgt_build_windows_bp(const uint32_t *pos, const uint64_t *run_len
             const size_t r0 = run_of(Glo), r1 = run_of(Ghi - 1);
             w.start = (uint32_t)(Glo - slot_base[r0]) + 1;       // dxywin[0].first
             w.end = (uint32_t)(Ghi - 1 - slot_base[r1]) + 1;     // dxywin[nsites-1].first
-            out[em.count] = w;
-        }
-        ++em.count;
-    });
-    *n_out = em.count;
-    if (out && em.count > cap) return fail(PGT_ECAP, "pgt_build_windows_bp: output capacity too small");
+            out[i] = w;
+        });
+    if (out && count > cap) return fail(PGT_ECAP, "pgt_build_windows_bp: output capacity too small");
     return PGT_OK;
 }
 

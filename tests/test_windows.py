@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import helpers
+import synth
 from popgenomicstools_amd import _lib
 
 
@@ -157,3 +158,33 @@ def test_extreme_builder_domain(pgt):
         pgt.build_windows_extreme(np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint64), None, 10)
     with pytest.raises(_lib.PgtError):
         pgt.build_windows_extreme(np.array([5], dtype=np.uint32), np.array([1], dtype=np.uint64), None, 0)
+
+
+def test_large_tables_take_the_parallel_fill_and_stay_equal(pgt, oracle):
+    """More than 2^20 windows (the -stepsize 1 regime): the table is filled by index in parallel chunks; it
+    must still be the streaming machine's sequence, and counting (out = NULL) must agree with filling."""
+    rng = np.random.default_rng(99)
+    n = 2_400_000
+    chr_ids, pos = synth.chromosomes(rng, n, 9, equal=False)
+    a = np.ones(n)
+    for W, S in ((50, 1), (64, 3)):
+        win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+        ref = oracle.fst_scan(chr_ids, pos, a, a, W, S)
+        assert win.size == ref.size and (W, S) != (50, 1) or win.size > (1 << 20)
+        assert np.array_equal(win["lo"], ref["lo"]) and np.array_equal(win["hi"], ref["hi"])
+        assert np.array_equal(win["label_run"], ref["label"])
+    # bp mode, many windows: against the oracle's slot machine
+    m = 300_000
+    chr_ids, pos = synth.chromosomes(rng, m, 3, equal=False)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, m)
+    rl = pgt.run_lengths(chr_ids)
+    ends = np.cumsum(rl).astype(np.int64) - 1
+    chr_len = (pos[ends] + 17).astype(np.uint32)
+    win = pgt.build_windows_bp(pos, rl, chr_len, 40, 2)
+    ref, _ = oracle.dxy_scan(chr_ids, pos, p1, p2, n1, n2, 40, 2, 1, 0, 0, run_chr_len=chr_len)
+    assert win.size == ref.size > (1 << 20)
+    ne = ref["hi"] > ref["lo"]  # an empty window's [lo, hi) is any empty range
+    assert np.array_equal(win["hi"] > win["lo"], ne)
+    assert np.array_equal(win["lo"][ne], ref["lo"][ne]) and np.array_equal(win["hi"][ne], ref["hi"][ne])
+    assert np.array_equal(win["start"], ref["start"]) and np.array_equal(win["end"], ref["end"])
+    assert np.array_equal(win["label_run"], ref["label"])
