@@ -6,7 +6,6 @@ config 5  fstWindow, 28 population pairs x 10^8 sites, one table, 448 B/site (al
 plus the host-buffer entry point (PCIe included) for the record."""
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -19,6 +18,10 @@ from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 
 
 def timed(ctx, fn, reps=12):
+    """-> (build kernel ms, query kernel ms, whole step ms), medians.  Kernel times: the library's HIP events
+    around the build and the query launches; whole step: torch events on the launch stream around one call
+    (round 1 divided a host-timed loop of 12 calls by 12, which charged the idle GPU's wake-up and the
+    host's launch latency of the first call to every step: 0.57 ms for a 0.29 ms step)."""
     ctx.set_profiling(True)
     b, q = [], []
     for r in range(reps + 2):
@@ -28,11 +31,13 @@ def timed(ctx, fn, reps=12):
             b.append(bm); q.append(qm)
     ctx.set_profiling(False)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
         fn()
+        e1.record()
     torch.cuda.synchronize()
-    return float(np.median(b)), float(np.median(q)), (time.perf_counter() - t0) / reps * 1e3
+    return float(np.median(b)), float(np.median(q)), float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
 
 
 def main():
@@ -106,6 +111,7 @@ def main():
     m = 50_000_000
     hp, ha, hb = pos[:m].cpu().numpy().view(np.uint32), a[:m].cpu().numpy(), b[:m].cpu().numpy()
     hw = pgt.build_windows_sites(np.full(10, m // 10, dtype=np.uint64), W, S)
+    import time
     ctx.fst_reduce(hp, ha, hb, hw)
     t0 = time.perf_counter()
     for _ in range(3):
