@@ -207,6 +207,7 @@ __device__ __forceinline__ void het_count_word(uint32_t w, uint32_t &nonmiss, ui
 // WORKGROUP per level-2 tile, 16 leaf tiles per wave, level 2 summed through LDS so that the tree_up launch
 // disappears: 35 us instead of 30 at 10^8 sites, 0.162 instead of 0.158 ms at 10^9 — fewer, fatter items.)
 constexpr int kHetChunk = 8;
+constexpr uint64_t kHetSmallItems = 30000;  // 8192-site work items (2.5e8 sites) up to which the 128-VGPR build is used
 __device__ __forceinline__ void het_build_body(const int8_t *__restrict__ g, uint64_t n, uint64_t n_items,
                                                const TreeView &tv) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -256,6 +257,10 @@ __device__ __forceinline__ void het_build_body(const int8_t *__restrict__ g, uin
 }
 
 __global__ __launch_bounds__(256) void het_build_kernel(const int8_t *g, uint64_t n, uint64_t n_items, TreeView tv) {
+    het_build_body(g, n, n_items, tv);
+}
+// the same with at least 4 waves per SIMD (at most 128 VGPRs; left alone the compiler spends 254 on this body)
+__global__ __launch_bounds__(256, 4) void het_build_kernel_w4(const int8_t *g, uint64_t n, uint64_t n_items, TreeView tv) {
     het_build_body(g, n, n_items, tv);
 }
 
@@ -1112,7 +1117,13 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);
-        hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
+        // short inputs live on many short work items and want the waves (128-VGPR build, 16 waves per CU): 27.4 vs
+        // 29.7 us at 1e8 sites; long ones stream better with the 254-VGPR build: 164 vs 172 us at 1e9 (interleaved
+        // A/B in one process)
+        if (n_items <= kHetSmallItems)
+            hipLaunchKernelGGL(het_build_kernel_w4, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
+        else
+            hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
         if (int rc = hip_fail(hipGetLastError(), "het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeHet>(tl, tv, 1, s, err, 1, n_items * kHetChunk)) return rc;
     }
