@@ -13,7 +13,7 @@ CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
 BIN      := $(PKG)/bin
 LIB      := $(PKG)/libpgtwin.so
-LIBSRC   := $(CSRC)/pgt_kernels.hip $(CSRC)/pgt_af_kernels.hip $(CSRC)/pgt_api.cpp $(CSRC)/pgt_windows.cpp
+LIBSRC   := $(CSRC)/pgt_kernels.hip $(CSRC)/pgt_af_kernels.hip $(CSRC)/pgt_ingest.hip $(CSRC)/pgt_api.cpp $(CSRC)/pgt_windows.cpp
 LIBHDR   := $(CSRC)/pgt_internal.h $(CSRC)/pgt_device.h include/pgtwin.h
 LIBFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 TOOLS    := fstWindow hetWindow dxyWindow ihsWindow xpehhWindow

@@ -252,6 +252,52 @@ int pgt_rowbuf_open(pgt_ctx *ctx, const pgt_ipc_handle *handle, void **dev_ptr);
 int pgt_rowbuf_close(pgt_ctx *ctx, void *dev_ptr, int owner);
 int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, void *stream);
 
+/* ---- device-side text ingest ------------------------------------------------ */
+/* Replaces the per-line text parse of the reference's streaming loops (fstWindow.cpp:123-146 `chr pos a b`,
+ * hetWindow.cpp:121-144 `chr pos genotype`, dxyWindow.cpp:141-153,399-403 `chr pos major minor ref freq nInd`):
+ * the raw text is copied to the GPU once and parsed there into the structure-of-arrays columns the
+ * *_reduce_dev entry points take, together with the chromosome runs pgt_build_windows_* take.
+ *   text, len   the lines to parse, in HOST memory (a header line, if any, already skipped by the caller)
+ *   tokens      what the whitespace-separated tokens of a line are, in order; tokens[0] must be PGT_TOK_CHR
+ *               (2 <= n_tokens <= 8); tokens beyond n_tokens are ignored, as the tools ignore extra columns
+ * Semantics of the tools' own loops are kept: a blank line ends the data (fstWindow.cpp:125); a last line
+ * without newline is accepted; \r counts as blank.  Numbers the kernel cannot convert exactly in one f64
+ * operation (more than 15 significant digits, |power of ten| > 22, inf, nan, odd signs) are converted on the
+ * host with the correctly rounded library routine, so every value has the bits `ss >> double` gives.
+ * pgt_ingest_bad_line: 0-based index of the first line (before the end of data) that cannot be parsed, or -1;
+ * rows then holds the number of good lines before it, and the caller reports the error as the tools would.
+ * PGT_EDOMAIN: more than 2^20 chromosome runs or irregular lines — parse such an input on the host.
+ * Column k (pgt_ingest_column) belongs to token k: u32 for PGT_TOK_U32, f64 for _F64 / _FREQ, i8 for _I8,
+ * i32 for _I32, NULL for _CHR / _SKIP; DEVICE pointers, rows elements, owned by the ingest object.
+ * pgt_ingest_runs: run lengths, and for every run the byte offset and length of its name inside `text`. */
+enum {
+    PGT_TOK_CHR = 0,  /* chromosome name: delimits the runs, not stored */
+    PGT_TOK_SKIP = 1, /* ignored (MAF major / minor / ref) */
+    PGT_TOK_U32 = 2,  /* position */
+    PGT_TOK_F64 = 3,  /* any double */
+    PGT_TOK_I8 = 4,   /* integer, clamped to int8 (hetWindow genotype: only >= 0 and == 1 are ever tested) */
+    PGT_TOK_I32 = 5,  /* integer, clamped to int32 (MAF nInd) */
+    PGT_TOK_FREQ = 6  /* double that must lie in [0,1] (MAF allele frequency), else the line is an error */
+};
+typedef struct pgt_ingest pgt_ingest;
+/* reductions over DEVICE columns (pgt_ingest_column) with the window table and the rows in HOST memory:
+ * the host-buffer entry points minus the column upload; synchronous */
+int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, const double *d_b, uint64_t n,
+                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out);
+int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, uint64_t n,
+                        const pgt_win *win, uint64_t n_win, pgt_het_row *out);
+int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2,
+                        const int32_t *d_n1, const int32_t *d_n2, uint64_t n, int minind,
+                        const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot);
+/* device column of token `token` -> host (bytes = rows * element size) */
+int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
+int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
+uint64_t pgt_ingest_rows(const pgt_ingest *ing);
+int64_t pgt_ingest_bad_line(const pgt_ingest *ing);
+void *pgt_ingest_column(const pgt_ingest *ing, int token);
+size_t pgt_ingest_runs(const pgt_ingest *ing, const uint64_t **run_len, const uint64_t **name_off, const uint32_t **name_len);
+void pgt_ingest_free(pgt_ingest *ing);
+
 #ifdef __cplusplus
 }
 #endif

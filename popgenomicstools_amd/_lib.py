@@ -45,7 +45,9 @@ SYMBOLS = [
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
     "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
+    "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
 ]
+PGT_TOK_CHR, PGT_TOK_SKIP, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_FREQ = range(7)
 
 
 class PgtError(RuntimeError):
@@ -109,6 +111,21 @@ def load() -> C.CDLL:
     lib.pgt_rowbuf_open.argtypes = [vp, vp, C.POINTER(vp)]
     lib.pgt_rowbuf_close.argtypes = [vp, vp, i32]
     lib.pgt_rowbuf_read.argtypes = [vp, vp, vp, sz, vp]
+    lib.pgt_fst_reduce_cols.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp]
+    lib.pgt_het_reduce_cols.argtypes = [vp, vp, vp, u64, vp, u64, vp]
+    lib.pgt_dxy_reduce_cols.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp]
+    lib.pgt_ingest_download.argtypes = [vp, vp, i32, vp, sz]
+    lib.pgt_ingest_text.argtypes = [vp, vp, sz, vp, i32, C.POINTER(vp)]
+    lib.pgt_ingest_rows.restype = u64
+    lib.pgt_ingest_rows.argtypes = [vp]
+    lib.pgt_ingest_bad_line.restype = C.c_int64
+    lib.pgt_ingest_bad_line.argtypes = [vp]
+    lib.pgt_ingest_column.restype = vp
+    lib.pgt_ingest_column.argtypes = [vp, i32]
+    lib.pgt_ingest_runs.restype = sz
+    lib.pgt_ingest_runs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.pgt_ingest_free.restype = None
+    lib.pgt_ingest_free.argtypes = [vp]
     for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
         getattr(lib, name)
     _lib = lib

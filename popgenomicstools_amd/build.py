@@ -19,7 +19,7 @@ BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libpgtwin.so")
 FLAGS = os.path.join(PKG, "libpgtwin.flags")
 
-LIB_SOURCES = ["pgt_kernels.hip", "pgt_af_kernels.hip", "pgt_api.cpp", "pgt_windows.cpp"]
+LIB_SOURCES = ["pgt_kernels.hip", "pgt_af_kernels.hip", "pgt_ingest.hip", "pgt_api.cpp", "pgt_windows.cpp"]
 HOST_TOOLS = ["fstWindow", "hetWindow", "dxyWindow", "ihsWindow", "xpehhWindow"]
 
 

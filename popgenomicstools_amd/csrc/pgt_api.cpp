@@ -338,6 +338,13 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
                       ctx->hints);
 }
 
+/* ---------------- device-side text ingest ---------------- */
+
+int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out) {
+    PGT_USE_DEVICE(ctx);
+    return ingest_text(ctx->device, text, len, tokens, n_tokens, out, &ctx->error);
+}
+
 /* ---------------- multi-GPU row exchange ---------------- */
 
 static_assert(sizeof(hipIpcMemHandle_t) == PGT_IPC_HANDLE_BYTES, "pgt_ipc_handle must hold a hipIpcMemHandle_t");
@@ -410,22 +417,19 @@ int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, u
 }
 
 
-int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
-                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
+/* device columns (e.g. from pgt_ingest_text), window table and rows in HOST memory */
+int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, const double *d_b, uint64_t n,
+                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
     PGT_USE_DEVICE(ctx);
-    if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    if ((n && (!d_pos || !d_a || !d_b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
-    DevBuf dpos, da, db, dwin, dout, dtree;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
-    if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+    DevBuf dwin, dout, dtree;
     if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
     if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
     const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_fst_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(da.p),
-                                    static_cast<double *>(db.p), n, static_cast<pgt_win *>(dwin.p), n_win,
+    if (int rc = pgt_fst_reduce_dev(ctx, d_pos, d_a, d_b, n, static_cast<pgt_win *>(dwin.p), n_win,
                                     static_cast<pgt_fst_row *>(dout.p), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
@@ -433,25 +437,69 @@ int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const dou
     return PGT_OK;
 }
 
-int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
-                   uint64_t n_win, pgt_het_row *out) {
+int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
+                   const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
     PGT_USE_DEVICE(ctx);
-    if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    DevBuf dpos, da, db;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
+    if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+    return pgt_fst_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(da.p), static_cast<double *>(db.p), n,
+                               win, n_win, out);
+}
+
+int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, uint64_t n, const pgt_win *win,
+                        uint64_t n_win, pgt_het_row *out) {
+    PGT_USE_DEVICE(ctx);
+    if ((n && (!d_pos || !d_g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
-    DevBuf dpos, dg, dwin, dout, dtree;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+    DevBuf dwin, dout, dtree;
     if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
     if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
     const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_het_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n,
-                                    static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_het_row *>(dout.p),
+    if (int rc = pgt_het_reduce_dev(ctx, d_pos, d_g, n, static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_het_row *>(dout.p),
                                     dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
     if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
+    return PGT_OK;
+}
+
+int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
+                   uint64_t n_win, pgt_het_row *out) {
+    PGT_USE_DEVICE(ctx);
+    if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    DevBuf dpos, dg;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+    return pgt_het_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n, win, n_win, out);
+}
+
+int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2, const int32_t *d_n1,
+                        const int32_t *d_n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
+                        pgt_dxy_row *out, pgt_dxy_total *tot) {
+    PGT_USE_DEVICE(ctx);
+    if ((n && (!d_pos || !d_p1 || !d_p2 || !d_n1 || !d_n2)) || (n_win && (!win || !out)))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
+    DevBuf dwin, dout, dtot, dtree;
+    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
+    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
+    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_dxy_reduce_dev(ctx, d_pos, d_p1, d_p2, d_n1, d_n2, n, minind, static_cast<pgt_win *>(dwin.p), n_win,
+                                    static_cast<pgt_dxy_row *>(dout.p), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr,
+                                    dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
+    if (n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
+    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
     return PGT_OK;
 }
 
@@ -461,30 +509,24 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
     PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !p1 || !p2 || !n1 || !n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
-    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
-    const HintScope hint(ctx, win, n_win);
-    DevBuf dpos, d1, d2, dn1, dn2, dwin, dout, dtot, dtree;
+    DevBuf dpos, d1, d2, dn1, dn2;
     if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
     if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;
     if (int rc = d2.upload(ctx, p2, n * sizeof(double), "upload p2")) return rc;
     if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
     if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
-    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
-    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
-    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_dxy_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p),
-                                    static_cast<double *>(d2.p), static_cast<int32_t *>(dn1.p),
-                                    static_cast<int32_t *>(dn2.p), n, minind, static_cast<pgt_win *>(dwin.p), n_win,
-                                    static_cast<pgt_dxy_row *>(dout.p), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr,
-                                    dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
-    if (n_win)
-        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
-    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
-    return PGT_OK;
+    return pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p), static_cast<double *>(d2.p),
+                               static_cast<int32_t *>(dn1.p), static_cast<int32_t *>(dn2.p), n, minind, win, n_win, out, tot);
+}
+
+/* copy of a device column of an ingest object to the host (dxyWindow's site synchronisation and bp-window
+ * table work on host positions) */
+int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes) {
+    PGT_USE_DEVICE(ctx);
+    void *src = pgt_ingest_column(ing, token);
+    if (bytes == 0) return PGT_OK;
+    if (!src || !host_dst) return ctx_fail(ctx, PGT_EARG, "pgt_ingest_download: no such column");
+    return hip_check(ctx, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost), "pgt_ingest_download");
 }
 
 }  // extern "C"

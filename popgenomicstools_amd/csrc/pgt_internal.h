@@ -146,6 +146,9 @@ int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *
                   uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
 
+// pgt_ingest.hip: text -> device columns + chromosome runs (synchronous, default stream of `device`)
+int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err);
+
 int init_kernels(std::string *err);     // pgt_kernels.hip: one-time kernel attributes (called by pgt_open)
 int init_af_kernels(std::string *err);  // pgt_af_kernels.hip
 

@@ -40,10 +40,20 @@ static void help(unsigned W, unsigned S, int minind, int fixedsite, int skip_mis
 
 struct Maf {
     Runs runs;
+    DeviceTable dev;  // set when the file was parsed on the GPU: pos / freq / nind are then tokens 1 / 5 / 6 there
+    bool on_device = false;
     Column<uint32_t> pos;
     Column<double> freq;
     Column<int32_t> nind;
     size_t n = 0;
+    void reset() {  // back to empty: the host parser fills it from scratch
+        if (dev.ing) pgt_ingest_free(dev.ing);
+        dev.ing = nullptr;
+        dev.n = 0;
+        on_device = false;
+        runs = Runs{};
+        n = 0;
+    }
     void alloc(size_t rows) { pos.alloc(rows); freq.alloc(rows); nind.alloc(rows); }
     // chr pos major minor ref freq nind — only chr, pos, freq, nind are used (dxyWindow.cpp:141-153)
     bool parse_line(Cursor &c, size_t i, Runs &r) {
@@ -61,6 +71,31 @@ struct Maf {
     }
 };
 
+static const char *const kMafWhat = "dxyWindow: cannot parse MAF line (chr pos major minor ref freq nind, freq in [0,1])";
+static const uint8_t kMafSpec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_SKIP, PGT_TOK_SKIP, PGT_TOK_SKIP, PGT_TOK_FREQ, PGT_TOK_I32};
+
+// the device path of read_maf (plain or gzipped text of at least 8 MiB, no column cache): only the position
+// column comes back to the host (site synchronisation and the bp-window table work on it)
+static bool read_maf_on_device(pgt_ctx *ctx, const Text &text, const char *path, Maf &m) {
+    Cursor hdr{text.begin(), text.end()};
+    hdr.next_line();  // header (dxyWindow.cpp:284)
+    if (!ingest_on_device(ctx, hdr.p, text.end(), kMafSpec, 7, kMafWhat, path, 2, m.dev, m.runs)) return false;
+    m.n = m.dev.n;
+    m.on_device = true;
+    m.pos.alloc(m.n);
+    check(pgt_ingest_download(ctx, m.dev.ing, 1, m.pos.data(), m.n * sizeof(uint32_t)), ctx);
+    return true;
+}
+// the remaining columns of a file parsed on the GPU, for the host-side merge of differing site sets
+static void fetch_columns(pgt_ctx *ctx, Maf &m) {
+    if (!m.on_device) return;
+    m.freq.alloc(m.n);
+    m.nind.alloc(m.n);
+    check(pgt_ingest_download(ctx, m.dev.ing, 5, m.freq.data(), m.n * sizeof(double)), ctx);
+    check(pgt_ingest_download(ctx, m.dev.ing, 6, m.nind.data(), m.n * sizeof(int32_t)), ctx);
+    m.on_device = false;
+}
+
 static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache) {
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(int32_t)}};
     if (cache.load(m.n, m.runs, cols)) {  // only with PGT_COLUMN_CACHE=<dir>; plain (not gzipped-by-name-only) regular files
@@ -73,8 +108,7 @@ static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &c
     if (!text.open(path)) die(std::string("Unable to open ") + which + " MAF file: " + path);
     Cursor hdr{text.begin(), text.end()};
     hdr.next_line();  // header (dxyWindow.cpp:284)
-    m.n = parse_table(hdr.p, text.end(), m, m.runs,
-                      "dxyWindow: cannot parse MAF line (chr pos major minor ref freq nind, freq in [0,1])", path, 2);
+    m.n = parse_table(hdr.p, text.end(), m, m.runs, kMafWhat, path, 2);
     if (cache.enabled()) {
         cols[0].data = m.pos.data(); cols[1].data = m.freq.data(); cols[2].data = m.nind.data();
         cache.store(m.n, m.runs, cols);
@@ -126,12 +160,25 @@ int main(int argc, char **argv) {
     DeviceOpener device;  // HIP start-up runs beside the parse
     Maf m1, m2;
     ColumnCache c1("dxyWindow maf", argv[argc - 2]), c2("dxyWindow maf", argv[argc - 1]);  // own the mappings the columns may borrow
-    {   // the two files are independent: parse them side by side
+    bool parsed = false;
+    if (!c1.enabled()) {  // large inputs: parse both files on the GPU, one after the other (one context, one thread)
+        Text t1, t2;
+        if (!t1.open(argv[argc - 2])) die(std::string("Unable to open Pop1 MAF file: ") + argv[argc - 2]);
+        if (!t2.open(argv[argc - 1])) die(std::string("Unable to open Pop2 MAF file: ") + argv[argc - 1]);
+        if (gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
+            pgt_ctx *c = device.get();
+            timer.lap("wait for HIP");
+            parsed = read_maf_on_device(c, t1, argv[argc - 2], m1) && read_maf_on_device(c, t2, argv[argc - 1], m2);
+            if (!parsed) { m1.reset(); m2.reset(); }
+            timer.lap(parsed ? "gpu parse" : "gpu parse (refused)");
+        }
+    }
+    if (!parsed) {  // the two files are independent: parse them side by side on the host
         std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1, c1); });
         read_maf(argv[argc - 1], "Pop2", m2, c2);
         t1.join();
+        timer.lap("parse");
     }
-    timer.lap("parse");
     if (m1.n == 0 || m2.n == 0) die("dxyWindow: a MAF file holds no sites");
     if (m1.runs.name[0] != m2.runs.name[0]) die("Chromosomes in MAF files differ");  // dxyWindow.cpp:295-298
 
@@ -147,11 +194,15 @@ int main(int argc, char **argv) {
     size_t n_sites = 0;
     const bool same_sites = m1.n == m2.n && m1.runs.name == m2.runs.name && m1.runs.len == m2.runs.len &&
                             std::memcmp(m1.pos.data(), m2.pos.data(), m1.n * sizeof(uint32_t)) == 0;
+    const bool on_device = same_sites && m1.on_device && m2.on_device;  // frequencies and counts stay on the GPU
     if (same_sites) {
+        if (!on_device) { fetch_columns(device.get(), m1); fetch_columns(device.get(), m2); }
         runs = m1.runs;
         pos = m1.pos.data(); p1 = m1.freq.data(); p2 = m2.freq.data(); n1 = m1.nind.data(); n2 = m2.nind.data();
         n_sites = m1.n;
     } else {
+        fetch_columns(device.get(), m1);
+        fetch_columns(device.get(), m2);
         size_t r1 = 0, r2 = 0, o1 = 0, o2 = 0;
         while (r1 < m1.runs.name.size() && r2 < m2.runs.name.size()) {
             const std::string &c1 = m1.runs.name[r1], &c2 = m2.runs.name[r2];
@@ -207,7 +258,11 @@ int main(int argc, char **argv) {
     timer.lap("wait for HIP");
     std::vector<pgt_dxy_row> rows(win.size());
     pgt_dxy_total tot{};
-    check(pgt_dxy_reduce(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
+    if (on_device)
+        check(pgt_dxy_reduce_cols(ctx, m1.dev.col<uint32_t>(1), m1.dev.col<double>(5), m2.dev.col<double>(5), m1.dev.col<int32_t>(6),
+                                  m2.dev.col<int32_t>(6), n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
+    else
+        check(pgt_dxy_reduce(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
     timer.lap("gpu reduce");
 
     // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)

@@ -45,22 +45,35 @@ int main(int argc, char **argv) {
     } tab;
     Runs runs;
     size_t n = 0;
+    DeviceTable dtab;  // the table when it was parsed on the GPU
+    Text text;         // the input text (not opened when the column cache answers)
     ColumnCache cache("fstWindow", argv[1]);  // only with PGT_COLUMN_CACHE=<dir>
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(double)}};
+    bool on_device = false;
     if (cache.load(n, runs, cols)) {
         tab.pos.borrow(static_cast<uint32_t *>(cols[0].data));
         tab.a.borrow(static_cast<double *>(cols[1].data));
         tab.b.borrow(static_cast<double *>(cols[2].data));
         timer.lap("cache map");
     } else {
-        Text text;
         if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
-        n = parse_table(text.begin(), text.end(), tab, runs, "fstWindow: cannot parse 'chr pos a b'", argv[1], 1);
-        timer.lap("parse");
-        if (cache.enabled()) {
-            cols[0].data = tab.pos.data(); cols[1].data = tab.a.data(); cols[2].data = tab.b.data();
-            cache.store(n, runs, cols);
-            timer.lap("cache write");
+        const char *what = "fstWindow: cannot parse 'chr pos a b'";
+        if (gpu_ingest_wanted(text.size())) {
+            static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64};
+            pgt_ctx *c = device.get();
+            timer.lap("wait for HIP");
+            on_device = ingest_on_device(c, text.begin(), text.end(), spec, 4, what, argv[1], 1, dtab, runs);
+            n = dtab.n;
+            timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
+        }
+        if (!on_device) {
+            n = parse_table(text.begin(), text.end(), tab, runs, what, argv[1], 1);
+            timer.lap("parse");
+            if (cache.enabled()) {
+                cols[0].data = tab.pos.data(); cols[1].data = tab.a.data(); cols[2].data = tab.b.data();
+                cache.store(n, runs, cols);
+                timer.lap("cache write");
+            }
         }
     }
 
@@ -74,7 +87,10 @@ int main(int argc, char **argv) {
     pgt_ctx *ctx = device.get();
     std::vector<pgt_fst_row> rows(n_win);
     timer.lap("wait for HIP");
-    check(pgt_fst_reduce(ctx, tab.pos.data(), tab.a.data(), tab.b.data(), n, win.data(), n_win, rows.data()), ctx);
+    if (on_device)
+        check(pgt_fst_reduce_cols(ctx, dtab.col<uint32_t>(1), dtab.col<double>(2), dtab.col<double>(3), n, win.data(), n_win, rows.data()), ctx);
+    else
+        check(pgt_fst_reduce(ctx, tab.pos.data(), tab.a.data(), tab.b.data(), n, win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");
 
     // chr start end mid fst nsites; %g == std::ostream default formatting (fstWindow.cpp:88)

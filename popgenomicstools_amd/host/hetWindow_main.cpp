@@ -50,21 +50,34 @@ int main(int argc, char **argv) {
     } tab;
     Runs runs;
     size_t n = 0;
+    DeviceTable dtab;  // the table when it was parsed on the GPU
+    Text text;         // the input text (not opened when the column cache answers)
     ColumnCache cache("hetWindow", argv[1]);  // only with PGT_COLUMN_CACHE=<dir>
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(int8_t)}};
+    bool on_device = false;
     if (cache.load(n, runs, cols)) {
         tab.pos.borrow(static_cast<uint32_t *>(cols[0].data));
         tab.g.borrow(static_cast<int8_t *>(cols[1].data));
         timer.lap("cache map");
     } else {
-        Text text;
         if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
-        n = parse_table(text.begin(), text.end(), tab, runs, "hetWindow: cannot parse 'chr pos genotype'", argv[1], 1);
-        timer.lap("parse");
-        if (cache.enabled()) {
-            cols[0].data = tab.pos.data(); cols[1].data = tab.g.data();
-            cache.store(n, runs, cols);
-            timer.lap("cache write");
+        const char *what = "hetWindow: cannot parse 'chr pos genotype'";
+        if (gpu_ingest_wanted(text.size())) {
+            static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8};
+            pgt_ctx *c = device.get();
+            timer.lap("wait for HIP");
+            on_device = ingest_on_device(c, text.begin(), text.end(), spec, 3, what, argv[1], 1, dtab, runs);
+            n = dtab.n;
+            timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
+        }
+        if (!on_device) {
+            n = parse_table(text.begin(), text.end(), tab, runs, what, argv[1], 1);
+            timer.lap("parse");
+            if (cache.enabled()) {
+                cols[0].data = tab.pos.data(); cols[1].data = tab.g.data();
+                cache.store(n, runs, cols);
+                timer.lap("cache write");
+            }
         }
     }
 
@@ -78,7 +91,10 @@ int main(int argc, char **argv) {
     pgt_ctx *ctx = device.get();
     std::vector<pgt_het_row> rows(n_win);
     timer.lap("wait for HIP");
-    check(pgt_het_reduce(ctx, tab.pos.data(), tab.g.data(), n, win.data(), n_win, rows.data()), ctx);
+    if (on_device)
+        check(pgt_het_reduce_cols(ctx, dtab.col<uint32_t>(1), dtab.col<int8_t>(2), n, win.data(), n_win, rows.data()), ctx);
+    else
+        check(pgt_het_reduce(ctx, tab.pos.data(), tab.g.data(), n, win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");
 
     // chr start end mid h nonmissing (hetWindow.cpp:87)

@@ -502,6 +502,42 @@ class DeviceOpener {
     std::thread th_;
 };
 
+// ---- device-side ingest (pgt_ingest_text) ---------------------------------------------------------
+// Above 8 MiB of text the table is parsed on the GPU (the text crosses PCIe once, the columns never visit
+// the host); below, the host parser is faster than HIP start-up and small inputs keep working without a GPU.
+// PGT_GPU_INGEST=0 forces the host parser, =1 the device one.  With PGT_COLUMN_CACHE the host path is taken
+// (the cache holds host columns).
+inline bool gpu_ingest_wanted(size_t text_bytes) {
+    if (const char *c = std::getenv("PGT_COLUMN_CACHE"); c && *c) return false;
+    if (const char *e = std::getenv("PGT_GPU_INGEST")) return std::atoi(e) != 0;
+    return text_bytes >= (8u << 20);
+}
+struct DeviceTable {
+    pgt_ingest *ing = nullptr;
+    size_t n = 0;
+    DeviceTable() = default;
+    DeviceTable(const DeviceTable &) = delete;
+    DeviceTable &operator=(const DeviceTable &) = delete;
+    ~DeviceTable() { if (ing) pgt_ingest_free(ing); }
+    template <class T> T *col(int token) const { return static_cast<T *>(pgt_ingest_column(ing, token)); }
+};
+// true: `tab` and `runs` hold the parsed table (errors in the text die here with the host parser's message);
+// false: the input has too many irregular lines for the device path — parse it on the host
+inline bool ingest_on_device(pgt_ctx *ctx, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what,
+                             const char *path, size_t first_line_no, DeviceTable &tab, Runs &runs) {
+    const int rc = pgt_ingest_text(ctx, b, (size_t)(e - b), spec, n_tokens, &tab.ing);
+    if (rc == PGT_EDOMAIN) return false;
+    check(rc, ctx);
+    const int64_t bad = pgt_ingest_bad_line(tab.ing);
+    if (bad >= 0) die(std::string(what) + " on line " + std::to_string(first_line_no + (size_t)bad) + " of " + path);
+    tab.n = (size_t)pgt_ingest_rows(tab.ing);
+    const uint64_t *len = nullptr, *off = nullptr;
+    const uint32_t *nlen = nullptr;
+    const size_t n_runs = pgt_ingest_runs(tab.ing, &len, &off, &nlen);
+    for (size_t r = 0; r < n_runs; ++r) runs.add(b + off[r], b + off[r] + nlen[r], len[r]);
+    return true;
+}
+
 // Window size / step size as fstWindow.cpp:51-64 reads them (atoi); zero, negative or
 // non-numeric values are refused.  The reference only warns for a bad step and then crashes
 // (SURVEY.md §4 Q9); a step larger than the window crashes it too.  Here all of these exit 255.

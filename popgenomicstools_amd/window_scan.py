@@ -110,6 +110,62 @@ class RowBuffer:
         return RowBuffer(self._ptr + offset, nbytes, self._owner or self)
 
 
+class DeviceColumn:
+    """A typed column in device memory that the library owns (pgt_ingest_column): accepted by the *_dev
+    wrappers wherever a CUDA tensor of that dtype is."""
+
+    def __init__(self, ptr: int, numel: int, dtype, owner):
+        self._ptr, self._numel, self.dtype, self._owner = int(ptr), int(numel), dtype, owner
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def numel(self) -> int:
+        return self._numel
+
+
+class Ingest:
+    """Result of Context.ingest_text: parsed columns on the GPU + chromosome runs on the host."""
+
+    def __init__(self, ctx, handle, text: bytes, tokens):
+        self._ctx, self._h, self._text, self.tokens = ctx, handle, text, list(tokens)
+        lib = ctx._lib
+        self.rows = int(lib.pgt_ingest_rows(handle))
+        self.bad_line = int(lib.pgt_ingest_bad_line(handle))
+        rl, off, ln = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)
+        n = int(lib.pgt_ingest_runs(handle, C.byref(rl), C.byref(off), C.byref(ln)))
+        arr = lambda p, t: np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=(n,)).copy() if n else np.zeros(0, dtype=t)  # noqa: E731
+        self.run_len = arr(rl, C.c_uint64)
+        offs, lens = arr(off, C.c_uint64), arr(ln, C.c_uint32)
+        self.run_names = [text[int(o): int(o) + int(k)].decode("latin-1") for o, k in zip(offs, lens)]
+
+    def column(self, token: int):
+        """Device column of token `token` (DeviceColumn), as the *_dev wrappers take it."""
+        import torch
+        dt = {_lib.PGT_TOK_U32: torch.int32, _lib.PGT_TOK_I32: torch.int32, _lib.PGT_TOK_F64: torch.float64,
+              _lib.PGT_TOK_FREQ: torch.float64, _lib.PGT_TOK_I8: torch.int8}[self.tokens[token]]
+        return DeviceColumn(self._ctx._lib.pgt_ingest_column(self._h, token), self.rows, dt, self)
+
+    def column_np(self, token: int) -> np.ndarray:
+        """Host copy of a column (u32 / i32 / f64 / i8 by token kind)."""
+        dt = {_lib.PGT_TOK_U32: np.uint32, _lib.PGT_TOK_I32: np.int32, _lib.PGT_TOK_F64: np.float64,
+              _lib.PGT_TOK_FREQ: np.float64, _lib.PGT_TOK_I8: np.int8}[self.tokens[token]]
+        ptr = self._ctx._lib.pgt_ingest_column(self._h, token)
+        raw = self._ctx.rowbuf_read(RowBuffer(ptr, self.rows * np.dtype(dt).itemsize)) if self.rows else np.zeros(0, np.uint8)
+        return raw.view(dt)
+
+    def free(self):
+        if self._h:
+            self._ctx._lib.pgt_ingest_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------------------
 # context
 # ---------------------------------------------------------------------------------------------
@@ -210,6 +266,8 @@ class Context:
         import torch
         if isinstance(t, RowBuffer) and dtype == torch.uint8:
             return t.data_ptr()
+        if isinstance(t, DeviceColumn) and t.dtype == dtype:
+            return t.data_ptr() if t.numel() else None
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
             raise PgtError(_lib.PGT_EARG, f"{name}: expected a contiguous CUDA tensor of {dtype}")
         return t.data_ptr() if t.numel() else None  # an empty shard passes NULL columns (n == 0)
@@ -226,6 +284,17 @@ class Context:
         """The C ABI gets no output capacity: an undersized buffer would be a silent device overrun."""
         if buf.numel() < need_bytes:
             raise PgtError(_lib.PGT_EARG, f"{name}: buffer holds {buf.numel()} bytes, {need_bytes} needed")
+
+    # ---- device-side text ingest (pgt_ingest_*) ---------------------------------------------
+    def ingest_text(self, text: bytes, tokens) -> Ingest:
+        """Parse whitespace-separated text lines on the GPU.  tokens: PGT_TOK_* per column, the first being
+        PGT_TOK_CHR (e.g. fstWindow: [CHR, U32, F64, F64]).  Raises PgtError(PGT_EDOMAIN) when the input
+        has too many irregular lines for the device path."""
+        toks = (C.c_uint8 * len(tokens))(*tokens)
+        h = C.c_void_p(0)
+        text = bytes(text)
+        self._check(self._lib.pgt_ingest_text(self._ctx, text if text else None, len(text), toks, len(tokens), C.byref(h)))
+        return Ingest(self, h, text, tokens)
 
     # ---- multi-GPU row buffer (pgt_rowbuf_*) ------------------------------------------------
     def rowbuf_create(self, nbytes: int):

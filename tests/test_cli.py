@@ -336,3 +336,61 @@ def test_column_cache_gives_the_same_tsv(hosts, tmp_path):
     changed = run(cmds[0], env=env)
     assert changed.returncode == 0 and changed.stdout == run(cmds[0]).stdout and changed.stdout != outputs[0]
     assert len(list(cache.glob("*.pgtcols"))) == 5
+
+
+# ---- device-side ingest (PGT_GPU_INGEST) against the host parser ---------------------------------------
+@pytest.mark.gpu
+def test_gpu_ingest_cli_equals_host_parser(hosts, tmp_path):
+    """Every host, the same command with the text parsed on the GPU (PGT_GPU_INGEST=1) and by the host parser
+    (=0): identical stdout, stderr and exit code — reference-made goldens, inputs with irregular numbers,
+    CRLF, blank-line stops, no trailing newline, and errors (the message carries the line number)."""
+    def both(cmd):
+        a = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1"))
+        b = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="0"))
+        assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), (cmd, a.stderr[-300:], b.stderr[-300:])
+        return a
+
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::4]
+    for c in cases:
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        r = both([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])])
+        assert r.returncode == 0
+        tsv_equal(r.stdout, c["stdout"], 4)
+    f = tmp_path / "odd.txt"
+    body = ("c1\t1\t0.1\t0.2\nc1 2 -0.000012 0.3\r\nc1\t3\t+0.5\t.5\n  c1 \t 4\t1.\t-.25  extra 7\nc1\t5\t1.5e-05\t1E5\n"
+            "c1\t6\t0.1234567890123456789\t123456789012345678\nc2\t7\t1e22\t1e23\nc2\t8\t4.9e-324\t2.2250738585072014e-308\n"
+            "c2\t9\tinf\t1\nc2\t10\tnan\t1\nc2\t+11\t+-1\t1\nc3\t00000000000000000012\t0.3\t0.4")
+    f.write_text(body)  # no trailing newline
+    assert both([hosts["fstWindow"], str(f), "3", "1"]).returncode == 0
+    f.write_text(body + "\n\nc9\tgarbage after the blank line\n")
+    assert both([hosts["fstWindow"], str(f), "3", "1"]).returncode == 0
+    for bad in ("c1\t1\t0.1\n", "c1\tx\t0.1\t0.2\n", "c1\t4294967296\t0.1\t0.2\n", "c1\t1\t1e400\t2\n", "c1\n"):
+        f.write_text("c1\t1\t0.1\t0.2\nc1\t2\t0.1\t0.2\n" + bad + "c1\t4\t0.1\t0.2\n")
+        r = both([hosts["fstWindow"], str(f), "2", "1"])
+        assert r.returncode == 255 and "line 3" in r.stderr
+    g = tmp_path / "het.txt"
+    g.write_text("cA 10 1\ncA 20 0\r\ncA 30 -1\ncA 40 2\ncA 50 +1\ncB 5 -9\ncB 9 300\n")
+    assert both([hosts["hetWindow"], str(g), "3", "2"]).returncode == 0
+    g.write_text("cA 10 1\ncA 20 1.5\n")
+    assert both([hosts["hetWindow"], str(g), "1", "1"]).returncode == 255
+    # dxyWindow: known answers (identical site sets -> columns stay on the GPU) and differing site sets (host merge)
+    k = helpers.load_golden("dxy_kat.json")
+    m1, m2, sz = tmp_path / "p1.mafs.gz", tmp_path / "p2.mafs", tmp_path / "sizes.txt"
+    _write_maf(m1, k["header"], k["pop1"], True)
+    _write_maf(m2, k["header"], k["pop2"])
+    sz.write_text("".join(f"{c}\t{n}\n" for c, n in k["sizes"]))
+    for c in k["cases"]:
+        cmd = [hosts["dxyWindow"], "-winsize", str(c["winsize"]), "-stepsize", str(c["stepsize"]),
+               "-minind", str(k["minind"]), "-fixedsite", str(c["fixedsite"]), "-skip_missing", str(c["skip_missing"])]
+        if not c["fixedsite"]:
+            cmd += ["-sizefile", str(sz)]
+        r = both(cmd + [str(m1), str(m2)])
+        assert r.returncode == 0 and r.stdout == c["stdout"] and r.stderr == c["stderr"]
+    sub = [row for i, row in enumerate(k["pop2"]) if i != 1]  # pop2 lacks one site of pop1
+    _write_maf(m2, k["header"], sub)
+    r = both([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-minind", "2", "-fixedsite", "1", str(m1), str(m2)])
+    assert r.returncode == 0 and r.stdout
+    _write_maf(m2, k["header"], [k["pop2"][0], ["cA", 3, 1.5, 4]])  # frequency outside [0,1]
+    r = both([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-fixedsite", "1", str(m1), str(m2)])
+    assert r.returncode == 255 and "line 3" in r.stderr
