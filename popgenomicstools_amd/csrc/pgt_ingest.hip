@@ -23,6 +23,9 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstring>
 #include <memory>
@@ -371,6 +374,16 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     auto hip = [&](hipError_t e, const char *what) {
         return e == hipSuccess ? PGT_OK : ingest_fail(err, PGT_EDEVICE, std::string("pgt_ingest_text: ") + what + ": " + hipGetErrorString(e));
     };
+    // PGT_HOST_TIMING=1 (the hosts' phase timer): where the ingest spends its time, on stderr
+    const bool timing = std::getenv("PGT_HOST_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pgt-host]   ingest: %-20s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::unique_ptr<pgt_ingest> ing(new pgt_ingest);
     ing->device = device;
     ing->n_tokens = n_tokens;
@@ -389,7 +402,12 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     const uint64_t n_blocks = (len + kBlockBytes - 1) / kBlockBytes;
     DevMem dtxt, dcount, dfirst, dtotal, dcnt, druns, dslow;
     if (int rc = hip(dtxt.alloc(n_blocks * kBlockBytes), "alloc text")) return rc;
+    lap("alloc text");
+    // one hipMemcpy of the pageable mapping: 25 GB/s (3.2 GB in 129 ms).  Tried: 4 threads staging interleaved
+    // 8-MiB chunks through their own pinned buffers and streams — 154 ms (the pinned allocations and the extra
+    // memcpy cost more than the overlap buys); kept simple.
     if (int rc = hip(hipMemcpy(dtxt.p, text, len, hipMemcpyHostToDevice), "upload text")) return rc;
+    lap("upload text");
     if (int rc = hip(hipMemsetAsync(static_cast<char *>(dtxt.p) + len, 0, n_blocks * kBlockBytes - len, nullptr), "pad text")) return rc;
     // 2. lines
     if (int rc = hip(dcount.alloc(n_blocks * sizeof(uint32_t)), "alloc counts")) return rc;
@@ -403,6 +421,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     uint64_t newlines = 0;
     if (int rc = hip(hipMemcpy(&newlines, dtotal.p, sizeof newlines, hipMemcpyDeviceToHost), "line count")) return rc;
     const uint64_t n_lines = newlines + 1;
+    lap("count lines");
     // 3. columns + parse
     Spec spec{};
     spec.n = n_tokens;
@@ -417,6 +436,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     if (int rc = hip(dcnt.alloc(sizeof(Counters)), "alloc counters")) return rc;
     if (int rc = hip(druns.alloc((size_t)kListCap * sizeof(ListEntry)), "alloc run list")) return rc;
     if (int rc = hip(dslow.alloc((size_t)kListCap * sizeof(ListEntry)), "alloc slow list")) return rc;
+    lap("alloc columns");
     Counters c0{~0ull, 0u, 0u};
     if (int rc = hip(hipMemcpy(dcnt.p, &c0, sizeof c0, hipMemcpyHostToDevice), "init counters")) return rc;
     hipLaunchKernelGGL(parse_lines_kernel, dim3((unsigned)n_blocks), dim3(kBlockThreads), 0, nullptr, txt, (uint64_t)len,
@@ -425,6 +445,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     if (int rc = hip(hipGetLastError(), "parse kernel")) return rc;
     Counters cnt{};
     if (int rc = hip(hipMemcpy(&cnt, dcnt.p, sizeof cnt, hipMemcpyDeviceToHost), "counters")) return rc;
+    lap("parse kernel");
     if (cnt.n_runs > kListCap || cnt.n_slow > kListCap)
         return ingest_fail(err, PGT_EDOMAIN, "pgt_ingest_text: more than 2^20 chromosome runs or irregular lines: parse this input on the host");
     const uint64_t n_rows = std::min<uint64_t>(n_lines, cnt.first_empty);
@@ -483,6 +504,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     }
     if (int rc = hip(hipDeviceSynchronize(), "ingest kernels")) return rc;
 
+    lap("slow lines + patches");
     // 5. chromosome runs of the good rows
     ing->rows = keep;
     for (size_t i = 0; i < runs.size() && runs[i].row < keep; ++i) {

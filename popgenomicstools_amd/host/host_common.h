@@ -139,6 +139,7 @@ class Text {
         madvise(map_, map_len_, MADV_SEQUENTIAL | MADV_WILLNEED);
         b_ = static_cast<const char *>(map_);
         e_ = b_ + map_len_;
+        prefault();
         return true;
     }
     const char *begin() const { return b_; }
@@ -146,6 +147,30 @@ class Text {
     size_t size() const { return (size_t)(e_ - b_); }
 
   private:
+    // Large inputs: map the page-cache pages into this process now, on all threads (MADV_POPULATE_READ, or
+    // one read per page where the kernel lacks it), instead of one fault at a time inside whoever reads the
+    // text first — the parser threads, or the single hipMemcpy that feeds the device parser.
+    void prefault() {
+        if (map_len_ < (64u << 20)) return;
+        unsigned T = std::thread::hardware_concurrency();
+        T = T ? (T > 32 ? 32 : T) : 1;
+        if (const char *e = std::getenv("PGT_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
+        const size_t page = 4096, per = ((map_len_ / T) + page - 1) / page * page;
+        std::vector<std::thread> th;
+        char *base = static_cast<char *>(map_);
+        for (unsigned t = 0; t < T; ++t) {
+            const size_t lo = per * t, hi = std::min(map_len_, lo + per);
+            if (lo >= hi) break;
+            th.emplace_back([=] {
+#ifdef MADV_POPULATE_READ
+                if (madvise(base + lo, hi - lo, MADV_POPULATE_READ) == 0) return;
+#endif
+                volatile char sink = 0;
+                for (size_t i = lo; i < hi; i += page) sink = sink + base[i];
+            });
+        }
+        for (auto &x : th) x.join();
+    }
     bool slurp(const char *path) {
         gzFile f = gzopen(path, "rb");
         if (!f) return false;
@@ -503,14 +528,17 @@ class DeviceOpener {
 };
 
 // ---- device-side ingest (pgt_ingest_text) ---------------------------------------------------------
-// Above 8 MiB of text the table is parsed on the GPU (the text crosses PCIe once, the columns never visit
-// the host); below, the host parser is faster than HIP start-up and small inputs keep working without a GPU.
-// PGT_GPU_INGEST=0 forces the host parser, =1 the device one.  With PGT_COLUMN_CACHE the host path is taken
-// (the cache holds host columns).
+// From 512 MiB of text on, the table is parsed on the GPU (the text crosses PCIe once, the columns never
+// visit the host).  Below that the host parser wins: it runs beside HIP start-up (60-200 ms on this pool),
+// which the device path has to wait for, and small inputs keep working without a GPU.  Measured at 10^8 lines
+// (profiles/r02/cli_end_to_end_1e8.md): fstWindow, 3.2 GB: 285 ms in-process on the device path (113 HIP
+// start-up, 129 upload at 25 GB/s, 18 parse kernel) against 402 ms with the host parser; dxyWindow, 2 x 0.7 GB:
+// 179 against 171 ms.  PGT_GPU_INGEST=0 forces the host parser, =1 the device one.  With PGT_COLUMN_CACHE the
+// host path is taken (the cache holds host columns).
 inline bool gpu_ingest_wanted(size_t text_bytes) {
     if (const char *c = std::getenv("PGT_COLUMN_CACHE"); c && *c) return false;
     if (const char *e = std::getenv("PGT_GPU_INGEST")) return std::atoi(e) != 0;
-    return text_bytes >= (8u << 20);
+    return text_bytes >= ((size_t)512 << 20);
 }
 struct DeviceTable {
     pgt_ingest *ing = nullptr;

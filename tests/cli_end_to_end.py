@@ -41,7 +41,11 @@ def main():
     for tool, path in (("fstWindow", f_fst), ("hetWindow", f_het)):
         env = dict(os.environ, PGT_HOST_TIMING="1")
         wall([os.path.join(BIN, tool), path, "50000", "10000"], env)  # warm the page cache / GPU runtime
+        # first the host parser (PGT_GPU_INGEST=0), then the default: text parsed on the GPU above 8 MiB
+        t_h, r_h = wall([os.path.join(BIN, tool), path, "50000", "10000"], dict(env, PGT_GPU_INGEST="0"))
+        ph = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_h.stderr.decode().splitlines() if "pgt-host" in ln)
         t_new, r_new = wall([os.path.join(BIN, tool), path, "50000", "10000"], env)
+        print(f"| {tool}, host parser (PGT_GPU_INGEST=0) | | {t_h:.2f} | | {len(r_h.stdout.splitlines())} | {r_h.stdout == r_new.stdout} (vs device parse) | {ph} |")
         ref = oracle_bind.ref_binary(tool)
         if ref:
             t_ref, r_ref = wall([ref, path, "50000", "10000"])
