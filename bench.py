@@ -56,7 +56,7 @@ BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
 SEED = 12345
 
 
-def cpu_baseline(pos, a, b, genome, W, S, n_sample):
+def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload:
     the first n_sample sites written as the tool's text input, then the UNMODIFIED reference binary
     (oracle/_ref/fstWindow, kind "reference") — or, if that binary did not travel, our restatement
@@ -81,6 +81,25 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample):
         assert orc.fst_text(path, W, S, os.devnull) == 0
         kind = "port"
     dt = time.perf_counter() - t0
+    if ctx is not None and extra is not None:
+        # the same text through the device-side ingest (pgt_ingest_text): the parsed columns must equal the resident ones
+        from popgenomicstools_amd._lib import PGT_TOK_CHR, PGT_TOK_F64, PGT_TOK_U32
+        text = open(path, "rb").read()
+        t1 = time.perf_counter()
+        ing = ctx.ingest_text(text, [PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64])
+        t_ing = time.perf_counter() - t1
+        assert ing.rows == n_sample and ing.bad_line == -1, ("ingest rows", ing.rows, n_sample, ing.bad_line)
+        assert ing.run_len.tolist() == np.bincount(chr_ids).tolist(), ("ingest runs", ing.run_len.tolist()[:4])
+        for tok, ref_col in ((1, hp), (2, ha), (3, hb)):  # == (the text cannot tell -0.0 written as 0.000000 apart)
+            got = ing.column_np(tok)
+            ne = np.flatnonzero(got != ref_col)
+            assert ne.size == 0, ("ingest column", tok, int(ne.size), int(ne[0]), got[ne[0]], ref_col[ne[0]])
+        extra["ingest_text"] = {"config": f"pgt_ingest_text on the CPU-baseline sample: {n_sample} lines, {len(text)} bytes of text -> pos, a, b "
+                                          "columns on the GPU + chromosome runs (upload included)",
+                                "seconds": t_ing, "lines_per_s": n_sample / t_ing, "text_GB_per_s": len(text) / t_ing / 1e9,
+                                "columns_equal_resident": True}
+        ing.free()
+        del text
     os.unlink(path)
     os.rmdir(tmpdir)
     return {"value": n_sample / dt, "unit": "sites/s", "cores": 1, "kind": kind,
@@ -377,7 +396,7 @@ def main():
             extra = extra_configs(ctx, dev, W, S, tree)
             ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
         if not args.no_cpu:
-            cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites)
+            cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra)
 
     if rank == 0:
         per_gpu = [int(s["site_hi"] - s["site_lo"]) for s in shards]

@@ -14,7 +14,10 @@ multi-GPU run can materialise exactly its own shard [site_lo, site_hi) of ONE ge
     g1,g2      = genotype in {0,1,2,-1} with probabilities {.5,.3,.15,.05} from u(7|8, i)
 
 Chromosomes are n_chr runs of (almost) equal length.  All floating-point steps are single IEEE
-operations (multiply, round-half-even, divide), identical in numpy and torch on CPU or GPU.
+operations (multiply, round-half-even, divide), identical in numpy and torch on CPU or GPU — the
+division is written with a TENSOR divisor on purpose: torch turns `x / 1e6` with a Python scalar into
+`x * (1 / 1e6)` on the GPU, which is one ulp off the correctly rounded quotient for about a third of the
+values (found by bench.py's ingest check: the text "0.022537" parses to the quotient, not to the product).
 
 This is bench/test plumbing (torch as a device RNG), not part of the product: nothing under
 popgenomicstools_amd/ imports it.
@@ -37,6 +40,12 @@ def _s64(x: int) -> int:
     """uint64 constant as the int64 with the same bits (torch has no uint64 arithmetic)."""
     x &= _MASK
     return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _div(x, d: float):
+    """x / d as a true (correctly rounded) division on every device."""
+    import torch
+    return torch.div(x, torch.tensor(d, dtype=x.dtype, device=x.device))
 
 
 class SynthGenome:
@@ -139,17 +148,17 @@ class SynthGenome:
         b = torch.empty(hi - lo, dtype=torch.float64, device=dev)
         for c0 in range(lo, hi, self._CHUNK):
             c1 = min(hi, c0 + self._CHUNK)
-            bb = torch.round(self._u_t(COL_B, c0, c1, dev) * 0.3e6) / 1e6
+            bb = _div(torch.round(self._u_t(COL_B, c0, c1, dev) * 0.3e6), 1e6)
             b[c0 - lo: c1 - lo] = bb
-            a[c0 - lo: c1 - lo] = torch.round(bb * (self._u_t(COL_A, c0, c1, dev) * 0.7 - 0.1) * 1e6) / 1e6
+            a[c0 - lo: c1 - lo] = _div(torch.round(bb * (self._u_t(COL_A, c0, c1, dev) * 0.7 - 0.1) * 1e6), 1e6)
         return self.pos_t(lo, hi, dev), a, b
 
     def dxy_columns_t(self, lo, hi, dev):
         """-> (p1, p2 f64; n1, n2 int32) for sites [lo, hi) (minind = 5 in the BASELINE workload)."""
         import torch
         e = lambda dt: torch.empty(hi - lo, dtype=dt, device=dev)  # noqa: E731
-        p1 = self._fill(e(torch.float64), lo, hi, lambda x, y: torch.round(self._u_t(COL_P1, x, y, dev) * 1e6) / 1e6)
-        p2 = self._fill(e(torch.float64), lo, hi, lambda x, y: torch.round(self._u_t(COL_P2, x, y, dev) * 1e6) / 1e6)
+        p1 = self._fill(e(torch.float64), lo, hi, lambda x, y: _div(torch.round(self._u_t(COL_P1, x, y, dev) * 1e6), 1e6))
+        p2 = self._fill(e(torch.float64), lo, hi, lambda x, y: _div(torch.round(self._u_t(COL_P2, x, y, dev) * 1e6), 1e6))
         n1 = self._fill(e(torch.int32), lo, hi, lambda x, y: self._small_t(COL_N1, x, y, dev, 21).to(torch.int32))
         n2 = self._fill(e(torch.int32), lo, hi, lambda x, y: self._small_t(COL_N2, x, y, dev, 21).to(torch.int32))
         return p1, p2, n1, n2
@@ -168,7 +177,7 @@ class SynthGenome:
         """allele-frequency column of population k (U(0,1), 6 decimals)."""
         import torch
         return self._fill(torch.empty(hi - lo, dtype=torch.float64, device=dev), lo, hi,
-                          lambda x, y: torch.round(self._u_t(COL_FREQ0 + k, x, y, dev) * 1e6) / 1e6)
+                          lambda x, y: _div(torch.round(self._u_t(COL_FREQ0 + k, x, y, dev) * 1e6), 1e6))
 
     def pair_columns_t(self, pair, lo, hi, dev):
         """(a, b) component columns of population pair `pair` (config 5): the fst recipe on its own columns."""
@@ -178,7 +187,7 @@ class SynthGenome:
         ca, cb = 64 + 2 * pair, 65 + 2 * pair
         for c0 in range(lo, hi, self._CHUNK):
             c1 = min(hi, c0 + self._CHUNK)
-            bb = torch.round(self._u_t(cb, c0, c1, dev) * 0.3e6) / 1e6
+            bb = _div(torch.round(self._u_t(cb, c0, c1, dev) * 0.3e6), 1e6)
             b[c0 - lo: c1 - lo] = bb
-            a[c0 - lo: c1 - lo] = torch.round(bb * (self._u_t(ca, c0, c1, dev) * 0.7 - 0.1) * 1e6) / 1e6
+            a[c0 - lo: c1 - lo] = _div(torch.round(bb * (self._u_t(ca, c0, c1, dev) * 0.7 - 0.1) * 1e6), 1e6)
         return a, b

@@ -50,3 +50,21 @@ def test_other_columns_are_range_addressable():
     geno = full[4].numpy()
     assert set(np.unique(geno)) <= {-1, 0, 1, 2} and abs((geno == 0).mean() - 0.5) < 0.02 and abs((geno == -1).mean() - 0.05) < 0.01
     assert not torch.equal(full[4], full[5])  # the two genotype columns are different streams
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_torch_equals_numpy():
+    """The same bits on the GPU as on the host — including the division by 1e6, which torch would turn into a
+    multiplication by the reciprocal for a Python-scalar divisor (one ulp off for a third of the values)."""
+    g = SynthGenome(12345, 2_000_003, 5)
+    dev = torch.device("cuda", 0)
+    p, a, b = g.fst_columns_np(0, g.n)
+    tp, ta, tb = g.fst_columns_t(0, g.n, dev)
+    assert np.array_equal(p, tp.cpu().numpy().view(np.uint32))
+    assert a.tobytes() == ta.cpu().numpy().tobytes() and b.tobytes() == tb.cpu().numpy().tobytes()
+    lo, hi = 777_777, 1_500_001
+    sp, sa, sb = g.fst_columns_t(lo, hi, dev)
+    assert np.array_equal(p[lo:hi], sp.cpu().numpy().view(np.uint32)) and a[lo:hi].tobytes() == sa.cpu().numpy().tobytes()
