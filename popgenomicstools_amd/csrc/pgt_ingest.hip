@@ -42,6 +42,9 @@ constexpr int kBlockThreads = 256;
 constexpr uint64_t kBlockBytes = (uint64_t)kLaneBytes * kBlockThreads;  // 4 KiB of text per workgroup
 constexpr int kMaxTokens = 8;
 constexpr uint32_t kListCap = 1u << 20;  // slow lines / run starts the device may report before the host takes over
+constexpr uint64_t kMaxLine = 1u << 16;  // a lane never walks further than this through one line: longer lines (not
+                                         // the tools' tables) make the ingest refuse the input (PGT_EDOMAIN), the
+                                         // host parser takes it
 
 struct Spec {
     uint8_t tok[kMaxTokens];
@@ -113,10 +116,12 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *count
 }
 
 struct Token { uint64_t b, e; };
-__device__ __forceinline__ Token next_token(const char *txt, uint64_t &p, uint64_t len) {
-    while (p < len && is_blank(txt[p])) ++p;
+// `limit`: the walk stops there even without a separator (callers check p against it: line too long)
+__device__ __forceinline__ Token next_token(const char *txt, uint64_t &p, uint64_t len, uint64_t limit) {
+    if (limit > len) limit = len;
+    while (p < limit && is_blank(txt[p])) ++p;
     Token t{p, p};
-    while (p < len && !is_sep(txt[p])) ++p;
+    while (p < limit && !is_sep(txt[p])) ++p;
     t.e = p;
     return t;
 }
@@ -205,7 +210,12 @@ __device__ __forceinline__ void append(ListEntry *list, uint32_t *n, uint64_t ro
 __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t row, const Spec &spec, const Columns &cols,
                            Counters *cnt, ListEntry *runs, ListEntry *slow) {
     uint64_t p = s;
-    Token chr = next_token(txt, p, len);
+    const uint64_t limit = s + kMaxLine;
+    Token chr = next_token(txt, p, len, limit);
+    if (p >= limit && limit < len) {  // no end of line (or of token) within kMaxLine bytes: not for the device path
+        atomicAdd(&cnt->n_slow, kListCap + 1u);
+        return;
+    }
     if (chr.b == chr.e) {  // blank-only line: end of data (fstWindow.cpp:125)
         atomicMin(&cnt->first_empty, (unsigned long long)row);
         return;
@@ -214,16 +224,25 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
     bool new_run = row == 0;
     if (!new_run) {
         uint64_t q = s - 1;  // txt[s-1] is the newline that ends the previous line
-        while (q > 0 && txt[q - 1] != '\n') --q;
+        const uint64_t stop = s > kMaxLine ? s - kMaxLine : 0;
+        while (q > stop && txt[q - 1] != '\n') --q;
+        if (q == stop && stop > 0) {  // the previous line is longer than kMaxLine
+            atomicAdd(&cnt->n_slow, kListCap + 1u);
+            return;
+        }
         uint64_t pp = q;
-        const Token prev = next_token(txt, pp, s - 1);
+        const Token prev = next_token(txt, pp, s - 1, s - 1);
         new_run = prev.e - prev.b != chr.e - chr.b;
         for (uint64_t k = 0; !new_run && k < chr.e - chr.b; ++k) new_run = txt[prev.b + k] != txt[chr.b + k];
     }
     if (new_run) append(runs, &cnt->n_runs, row, chr.b, (uint32_t)(chr.e - chr.b));
     bool ok = true;
     for (int k = 1; k < spec.n && ok; ++k) {  // token 0 is the chromosome
-        const Token t = next_token(txt, p, len);
+        const Token t = next_token(txt, p, len, limit);
+        if (p >= limit && limit < len) {
+            atomicAdd(&cnt->n_slow, kListCap + 1u);
+            return;
+        }
         switch (spec.tok[k]) {
             case PGT_TOK_SKIP: ok = t.e > t.b; break;
             case PGT_TOK_U32: {

@@ -199,3 +199,14 @@ def test_ingested_columns_feed_the_scan(pgt, ctx, oracle):
     ref = ctx.fst_reduce(pos, a, b, pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S))
     assert rows.tobytes() == ref.tobytes()
     assert C.sizeof(C.c_void_p) == 8
+
+
+def test_absurdly_long_lines_are_refused_not_walked(ctx):
+    """A line of 300 KB is not one of the tools' tables: the device path refuses the input (PGT_EDOMAIN) instead
+    of letting one lane walk through it; the hosts then parse it themselves."""
+    text = b"c1\t1\t0.1\t0.2\n" + b"c1\t2\t" + b"7" * 300_000 + b"\t0.2\nc1\t3\t0.1\t0.2\n"
+    with pytest.raises(_lib.PgtError) as e:
+        ctx.ingest_text(text, FST)
+    assert e.value.code == _lib.PGT_EDOMAIN
+    ok = b"c1\t1\t0.1\t0.2\n" + b"c1\t2\t0.5\t0.2 " + b"x" * 60_000 + b"\nc1\t3\t0.1\t0.2\n"  # long but under the cap: extra columns
+    assert check(ctx, ok, FST) == 3
