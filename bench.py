@@ -154,6 +154,15 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     out["dxy_het_fused_1e8"] = dict(r, config="BASELINE configs[2]: dxyWindow + hetWindow x2, shared SoA, 1e8 sites, 1 GPU",
                                     kernel="dxy_het_build_kernel")
     del p1, p2, n1, n2, g1, g2
+    # the same 28 pairs from 8 allele-frequency columns (SURVEY 8f-2): 64 B/site instead of 448
+    fr = [g8.freq_t(k, 0, n8, dev) for k in range(8)]
+    nsamp = [10.0 + k for k in range(8)]
+    af_tree = torch.empty(int(pgt._lib.load().pgt_af_tree_bytes(8, n8)), dtype=torch.uint8, device=dev)
+    r = timed_config(ctx, lambda: ctx.fst_af_reduce_dev(pos, fr, nsamp, win, out=rows, tree=af_tree), 64.0 * n8, reps=8)
+    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
+    out["af8_pairs28_1e8"] = dict(r, config="SURVEY 8(f2): 28 pairs from 8 allele-frequency columns x 1e8 sites (WCFst on device)",
+                                  kernel="af_build_kernel<8>")
+    del fr, af_tree
     # config 5, one-GPU form: 28 population pairs batched over one table (grid.y = pair)
     al, bl = [a], [b]
     for p in range(1, 28):
@@ -165,15 +174,6 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     out["pairs28_1e8"] = dict(r, config="BASELINE configs[4], one-GPU form: fstWindow 28 pop-pairs x 1e8 sites batched",
                               kernel="fst_build_kernel (grid.y = 28)")
     del al, bl
-    # the same 28 pairs from 8 allele-frequency columns (SURVEY 8f-2): 64 B/site instead of 448
-    fr = [g8.freq_t(k, 0, n8, dev) for k in range(8)]
-    nsamp = [10.0 + k for k in range(8)]
-    af_tree = torch.empty(int(pgt._lib.load().pgt_af_tree_bytes(8, n8)), dtype=torch.uint8, device=dev)
-    r = timed_config(ctx, lambda: ctx.fst_af_reduce_dev(pos, fr, nsamp, win, out=rows, tree=af_tree), 64.0 * n8, reps=8)
-    r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
-    out["af8_pairs28_1e8"] = dict(r, config="SURVEY 8(f2): 28 pairs from 8 allele-frequency columns x 1e8 sites (WCFst on device)",
-                                  kernel="af_build_kernel<8>")
-    del fr, af_tree
     # ihsWindow-style extreme-score scan: one f64 score column, 100 kb windows
     from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS, PGT_STAT_EXT
     ewin_h = pgt.build_windows_extreme(pos.cpu().numpy().view(np.uint32), g8.run_len, None, 100_000)
