@@ -266,7 +266,8 @@ int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t by
  * host with the correctly rounded library routine, so every value has the bits `ss >> double` gives.
  * pgt_ingest_bad_line: 0-based index of the first line (before the end of data) that cannot be parsed, or -1;
  * rows then holds the number of good lines before it, and the caller reports the error as the tools would.
- * PGT_EDOMAIN: more than 2^20 chromosome runs or irregular lines — parse such an input on the host.
+ * PGT_EDOMAIN: a line longer than 64 KiB, or more than 2^20 chromosome runs or irregular lines — such an
+ * input is not one of the tools' tables; parse it on the host.
  * Column k (pgt_ingest_column) belongs to token k: u32 for PGT_TOK_U32, f64 for _F64 / _FREQ, i8 for _I8,
  * i32 for _I32, NULL for _CHR / _SKIP; DEVICE pointers, rows elements, owned by the ingest object.
  * pgt_ingest_runs: run lengths, and for every run the byte offset and length of its name inside `text`. */

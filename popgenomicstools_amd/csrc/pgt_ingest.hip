@@ -60,6 +60,7 @@ struct Columns {
 struct Counters {
     unsigned long long first_empty;  // smallest row of a blank-only line
     uint32_t n_runs, n_slow;         // entries appended (may exceed kListCap: overflow)
+    uint32_t refuse, pad_;           // set when a line is too long for a lane to walk
 };
 
 __device__ __forceinline__ bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r'; }
@@ -213,7 +214,7 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
     const uint64_t limit = s + kMaxLine;
     Token chr = next_token(txt, p, len, limit);
     if (p >= limit && limit < len) {  // no end of line (or of token) within kMaxLine bytes: not for the device path
-        atomicAdd(&cnt->n_slow, kListCap + 1u);
+        atomicExch(&cnt->refuse, 1u);
         return;
     }
     if (chr.b == chr.e) {  // blank-only line: end of data (fstWindow.cpp:125)
@@ -227,7 +228,7 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
         const uint64_t stop = s > kMaxLine ? s - kMaxLine : 0;
         while (q > stop && txt[q - 1] != '\n') --q;
         if (q == stop && stop > 0) {  // the previous line is longer than kMaxLine
-            atomicAdd(&cnt->n_slow, kListCap + 1u);
+            atomicExch(&cnt->refuse, 1u);
             return;
         }
         uint64_t pp = q;
@@ -240,7 +241,7 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
     for (int k = 1; k < spec.n && ok; ++k) {  // token 0 is the chromosome
         const Token t = next_token(txt, p, len, limit);
         if (p >= limit && limit < len) {
-            atomicAdd(&cnt->n_slow, kListCap + 1u);
+            atomicExch(&cnt->refuse, 1u);
             return;
         }
         switch (spec.tok[k]) {
@@ -456,7 +457,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     if (int rc = hip(druns.alloc((size_t)kListCap * sizeof(ListEntry)), "alloc run list")) return rc;
     if (int rc = hip(dslow.alloc((size_t)kListCap * sizeof(ListEntry)), "alloc slow list")) return rc;
     lap("alloc columns");
-    Counters c0{~0ull, 0u, 0u};
+    Counters c0{~0ull, 0u, 0u, 0u, 0u};
     if (int rc = hip(hipMemcpy(dcnt.p, &c0, sizeof c0, hipMemcpyHostToDevice), "init counters")) return rc;
     hipLaunchKernelGGL(parse_lines_kernel, dim3((unsigned)n_blocks), dim3(kBlockThreads), 0, nullptr, txt, (uint64_t)len,
                        static_cast<const uint64_t *>(dfirst.p), spec, cols, static_cast<Counters *>(dcnt.p),
@@ -465,8 +466,9 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     Counters cnt{};
     if (int rc = hip(hipMemcpy(&cnt, dcnt.p, sizeof cnt, hipMemcpyDeviceToHost), "counters")) return rc;
     lap("parse kernel");
-    if (cnt.n_runs > kListCap || cnt.n_slow > kListCap)
-        return ingest_fail(err, PGT_EDOMAIN, "pgt_ingest_text: more than 2^20 chromosome runs or irregular lines: parse this input on the host");
+    if (cnt.refuse || cnt.n_runs > kListCap || cnt.n_slow > kListCap)
+        return ingest_fail(err, PGT_EDOMAIN, "pgt_ingest_text: a line longer than 64 KiB, or more than 2^20 chromosome runs or irregular "
+                                             "lines: parse this input on the host");
     const uint64_t n_rows = std::min<uint64_t>(n_lines, cnt.first_empty);
     std::vector<ListEntry> runs(cnt.n_runs), slow(cnt.n_slow);
     if (cnt.n_runs)
