@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised differential fuzzer of the device-side ingest at CLI level: random fst / het / MAF files (random
+separators, number formats, CRLF, blank-line stops, missing newline at the end, a bad line now and then) through
+the hosts with PGT_GPU_INGEST=1 and =0: stdout, stderr and exit code must be identical.
+usage: python tests/ingest_fuzz.py [seconds] [seed]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "popgenomicstools_amd", "bin")
+
+
+def fmt_float(rng, x):
+    k = rng.integers(0, 10)
+    if k < 5:
+        return "%.6f" % x
+    if k == 5:
+        return "%.3e" % x
+    if k == 6:
+        return "%.17g" % x
+    if k == 7:
+        return ("+" if x >= 0 else "") + "%.4f" % x
+    if k == 8:
+        return "%g" % x
+    return "%.10f" % x
+
+
+def make_file(rng, path, kind):
+    n = int(rng.choice([rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 200000)]))
+    sep = ["\t", " ", "  ", " \t"][int(rng.integers(0, 4))]
+    eol = "\r\n" if rng.random() < 0.2 else "\n"
+    n_chr = int(rng.integers(1, 6))
+    chrs = np.sort(rng.integers(0, n_chr, n))
+    pos = np.cumsum(rng.integers(1, 60, n))
+    bad_at = int(rng.integers(0, n)) if rng.random() < 0.15 else -1
+    blank_at = int(rng.integers(0, n)) if rng.random() < 0.15 else -1
+    lines = []
+    if kind == "maf":
+        lines.append("chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd")
+    for i in range(n):
+        if i == blank_at:
+            lines.append(" " if rng.random() < 0.5 else "")
+        if kind == "fst":
+            toks = ["c%d" % chrs[i], str(pos[i]), fmt_float(rng, rng.normal(0, 0.05)), fmt_float(rng, rng.random() * 0.3)]
+        elif kind == "het":
+            toks = ["c%d" % chrs[i], str(pos[i]), str(int(rng.choice([0, 1, 2, -1, 3, -9])))]
+        else:
+            toks = ["c%d" % chrs[i], str(pos[i]), "A", "C", "A", fmt_float(rng, rng.random()), str(int(rng.integers(0, 21)))]
+        if i == bad_at:
+            j = int(rng.integers(1, len(toks)))
+            toks[j] = ["x", "1e", "--1", "", "0x1", "1e999"][int(rng.integers(0, 6))]
+        if rng.random() < 0.02:
+            toks.append("extra")
+        lines.append(sep.join(toks))
+    text = eol.join(lines) + (eol if rng.random() < 0.85 else "")
+    with open(path, "w", newline="") as f:
+        f.write(text)
+    return n
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    d = tempfile.mkdtemp(prefix="pgt_ingest_fuzz_")
+    t0, trials, last = time.time(), 0, time.time()
+    counts = {"fst": 0, "het": 0, "maf": 0, "errors": 0}
+    while time.time() - t0 < budget:
+        trials += 1
+        if time.time() - last > 30:
+            print(f"  ... {trials} trials, {time.time() - t0:.0f} s", flush=True)
+            last = time.time()
+        kind = ["fst", "het", "maf"][int(rng.integers(0, 3))]
+        W = int(rng.integers(1, 400))
+        S = int(rng.integers(1, W + 1))
+        if kind == "maf":
+            f1, f2 = os.path.join(d, "p1.mafs"), os.path.join(d, "p2.mafs")
+            state = rng.bit_generator.state
+            make_file(rng, f1, "maf")
+            if rng.random() < 0.7:  # same sites, other frequencies
+                rng2 = np.random.default_rng(int(rng.integers(0, 2**31)))
+                rng.bit_generator.state = state
+                make_file(rng, f2, "maf")
+                del rng2
+            else:
+                make_file(rng, f2, "maf")
+            cmd = [os.path.join(BIN, "dxyWindow"), "-winsize", str(W), "-stepsize", str(S), "-minind", "5", "-fixedsite", "1", f1, f2]
+        else:
+            f = os.path.join(d, kind + ".txt")
+            make_file(rng, f, kind)
+            cmd = [os.path.join(BIN, kind + "Window"), f, str(W), str(S)]
+        res = [subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST=m), timeout=120) for m in ("1", "0")]
+        a, b = res
+        if kind == "maf" and a.returncode == b.returncode == 255:
+            # both files may hold an error: the host parser reads them on two threads and reports whichever it meets
+            # first, the device path reads Pop1 first — the message must be the same up to the file it names
+            norm = lambda e: e.replace(b"p1.mafs", b"pX.mafs").replace(b"p2.mafs", b"pX.mafs")  # noqa: E731
+            a.stderr, b.stderr = norm(a.stderr), norm(b.stderr)
+        if (a.returncode, a.stdout, a.stderr) != (b.returncode, b.stdout, b.stderr):
+            keep = os.path.join(d, "FAILED")
+            print("MISMATCH", cmd, a.returncode, b.returncode, a.stderr[-200:], b.stderr[-200:], "files kept in", d)
+            sys.exit(1)
+        counts[kind] += 1
+        counts["errors"] += a.returncode != 0
+    print(f"ingest_fuzz: {trials} trials in {time.time() - t0:.0f} s, device ingest == host parser everywhere: {counts}")
+
+
+if __name__ == "__main__":
+    main()
