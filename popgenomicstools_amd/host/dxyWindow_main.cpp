@@ -96,7 +96,9 @@ static void fetch_columns(pgt_ctx *ctx, Maf &m) {
     m.on_device = false;
 }
 
-static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache) {
+// error: a message instead of an exit, so that the caller reports Pop1's problems before Pop2's whichever thread
+// met its problem first
+static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache, std::string &error) {
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(int32_t)}};
     if (cache.load(m.n, m.runs, cols)) {  // only with PGT_COLUMN_CACHE=<dir>; plain (not gzipped-by-name-only) regular files
         m.pos.borrow(static_cast<uint32_t *>(cols[0].data));
@@ -105,10 +107,14 @@ static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &c
         return;
     }
     Text text;
-    if (!text.open(path)) die(std::string("Unable to open ") + which + " MAF file: " + path);
+    if (!text.open(path)) {
+        error = std::string("Unable to open ") + which + " MAF file: " + path;
+        return;
+    }
     Cursor hdr{text.begin(), text.end()};
     hdr.next_line();  // header (dxyWindow.cpp:284)
-    m.n = parse_table(hdr.p, text.end(), m, m.runs, kMafWhat, path, 2);
+    m.n = parse_table(hdr.p, text.end(), m, m.runs, kMafWhat, path, 2, &error);
+    if (!error.empty()) return;
     if (cache.enabled()) {
         cols[0].data = m.pos.data(); cols[1].data = m.freq.data(); cols[2].data = m.nind.data();
         cache.store(m.n, m.runs, cols);
@@ -162,10 +168,8 @@ int main(int argc, char **argv) {
     ColumnCache c1("dxyWindow maf", argv[argc - 2]), c2("dxyWindow maf", argv[argc - 1]);  // own the mappings the columns may borrow
     bool parsed = false;
     if (!c1.enabled()) {  // large inputs: parse both files on the GPU, one after the other (one context, one thread)
-        Text t1, t2;
-        if (!t1.open(argv[argc - 2])) die(std::string("Unable to open Pop1 MAF file: ") + argv[argc - 2]);
-        if (!t2.open(argv[argc - 1])) die(std::string("Unable to open Pop2 MAF file: ") + argv[argc - 1]);
-        if (gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
+        Text t1, t2;  // a file that cannot be opened is left to the host path below, which reports Pop1's problems first
+        if (t1.open(argv[argc - 2]) && t2.open(argv[argc - 1]) && gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
             parsed = read_maf_on_device(c, t1, argv[argc - 2], m1) && read_maf_on_device(c, t2, argv[argc - 1], m2);
@@ -174,9 +178,12 @@ int main(int argc, char **argv) {
         }
     }
     if (!parsed) {  // the two files are independent: parse them side by side on the host
-        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1, c1); });
-        read_maf(argv[argc - 1], "Pop2", m2, c2);
+        std::string e1, e2;
+        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1, c1, e1); });
+        read_maf(argv[argc - 1], "Pop2", m2, c2, e2);
         t1.join();
+        if (!e1.empty()) die(e1);
+        if (!e2.empty()) die(e2);
         timer.lap("parse");
     }
     if (m1.n == 0 || m2.n == 0) die("dxyWindow: a MAF file holds no sites");

@@ -290,7 +290,7 @@ struct Column {
 // hangs on it).  Returns the number of rows; `runs` receives the chromosome runs.
 template <class Table>
 size_t parse_table(const char *b, const char *e, Table &tab, Runs &runs, const char *what, const char *path,
-                   size_t first_line_no) {
+                   size_t first_line_no, std::string *error = nullptr) {  // error: receives the message instead of exiting
     const size_t len = (size_t)(e - b);
     int T = host_threads();
     if (len < (1u << 20)) T = 1;
@@ -338,7 +338,10 @@ size_t parse_table(const char *b, const char *e, Table &tab, Runs &runs, const c
     for (int t = 0; t < T; ++t) {
         if (res[t].bad) {
             const size_t line_no = first_line_no + (size_t)std::count(b, res[t].bad, '\n');
-            die(std::string(what) + " on line " + std::to_string(line_no) + " of " + path);
+            const std::string msg = std::string(what) + " on line " + std::to_string(line_no) + " of " + path;
+            if (!error) die(msg);
+            *error = msg;
+            return 0;
         }
         runs.append(res[t].runs);
         n = off[t] + res[t].rows;
