@@ -996,3 +996,40 @@ def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt
                 parts.append(rows_from_device(o, FST_ROW_DTYPE))
             assert np.concatenate(parts).tobytes() == r1.tobytes(), (W, S, world)
     ctx.set_window_step(0)
+
+
+def test_sliding_query_with_batched_pairs_and_fused_statistics(pgt, ctx):
+    """The sliding strategy behind the other entry points: batched pairs (grid.y) equal their single calls bit
+    for bit at step 1; the fused dxy + het call equals the separate calls."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(909)
+    n, W, S, n_pairs = 200_000, 3_000, 1, 3
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    cols = [synth.fst_columns(rng, n) for _ in range(n_pairs)]
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+    wt = windows_to_device(win, dev)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    tp = t(pos.view(np.int32))
+    ta, tb = [t(c[0]) for c in cols], [t(c[1]) for c in cols]
+    ctx.set_window_step(S)
+    try:
+        out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, wt)
+        torch.cuda.synchronize()
+        rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+        for p in range(n_pairs):
+            single, _ = ctx.fst_reduce_dev(tp, ta[p], tb[p], wt)
+            torch.cuda.synchronize()
+            assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
+        p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+        g1 = synth.het_column(rng, n).astype(np.int8)
+        g2 = synth.het_column(rng, n).astype(np.int8)
+        d, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), t(g1), t(g2), 5, wt)
+        ds, tots, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wt)
+        hs, _ = ctx.het_reduce_dev(tp, t(g2), wt)
+        torch.cuda.synchronize()
+        assert rows_from_device(d, DXY_ROW_DTYPE).tobytes() == rows_from_device(ds, DXY_ROW_DTYPE).tobytes()
+        assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tots, DXY_TOTAL_DTYPE).tobytes()
+        assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
+    finally:
+        ctx.set_window_step(0)
