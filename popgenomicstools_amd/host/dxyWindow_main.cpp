@@ -275,8 +275,7 @@ int main(int argc, char **argv) {
     // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)
     write_rows(win.size(), longest_name(runs) + 80, [&](size_t i, char *o) -> size_t {
         if (!(rows[i].neff > 0 || !skip_missing)) return 0;
-        return (size_t)std::sprintf(o, "%s\t%u\t%u\t%g\t%u\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
-                                    rows[i].end, rows[i].sum, rows[i].neff, rows[i].nskip);
+        return put_row(o, runs.name[win[i].label_run], {rows[i].start, rows[i].end}, rows[i].sum, {rows[i].neff, rows[i].nskip});
     });
     // genome-wide line: stdout for the global run, stderr beside windows (dxyWindow.cpp:429-433)
     std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff,

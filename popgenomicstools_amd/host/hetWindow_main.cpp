@@ -99,8 +99,7 @@ int main(int argc, char **argv) {
 
     // chr start end mid h nonmissing (hetWindow.cpp:87)
     write_rows(n_win, longest_name(runs) + 80, [&](size_t i, char *o) {
-        return (size_t)std::sprintf(o, "%s\t%u\t%u\t%u\t%g\t%u\n", runs.name[win[i].label_run].c_str(), rows[i].start,
-                                    rows[i].end, rows[i].mid, rows[i].h, rows[i].nonmissing);
+        return put_row(o, runs.name[win[i].label_run], {rows[i].start, rows[i].end, rows[i].mid}, rows[i].h, {rows[i].nonmissing});
     });
     finish(timer);
 }

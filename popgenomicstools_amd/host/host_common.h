@@ -24,10 +24,12 @@
 #include <algorithm>
 #include <charconv>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <string>
 #include <thread>
@@ -453,6 +455,78 @@ class ColumnCache {
     void *map_ = nullptr;
     size_t map_len_ = 0;
 };
+
+// ---- number formatting of the TSV rows --------------------------------------------------------------
+// The tools print with `std::cout << double` = printf("%g") (fstWindow.cpp:88).  With one row per site
+// (-stepsize 1) that conversion is the slowest thing left: ~0.4 us per sprintf.  fmt_g6
+// produces the same bytes: the value is scaled to six significant digits by ONE exact power of ten (error
+// below 1.2e-10 of a unit in the last digit); unless the scaled value lies within 1e-6 of a rounding boundary
+// — then, and for nan / inf / magnitudes outside 1e-17..1e27, it simply calls snprintf — the rounded digits
+// are the ones printf finds from the exact binary value.  tests/host_parse_check.cpp compares the two on
+// tens of millions of values.
+inline char *put_u32(char *p, uint32_t v) {
+    char tmp[10];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+inline size_t fmt_g6(double v, char *o) {
+    static const double kP10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    char *p = o;
+    if (v == 0.0) {
+        if (std::signbit(v)) *p++ = '-';
+        *p++ = '0';
+        return (size_t)(p - o);
+    }
+    const double a = std::fabs(v);
+    if (!(a >= 1e-17 && a < 1e27)) return (size_t)std::snprintf(o, 32, "%g", v);  // also nan and inf
+    int X = (int)std::floor(std::log10(a));  // decimal exponent, possibly one off next to a power of ten
+    auto scale = [&](int x) { return 5 - x >= 0 ? a * kP10[5 - x] : a / kP10[x - 5]; };
+    double sc = scale(X);
+    if (sc < 1e5) sc = scale(--X);
+    else if (sc >= 1e6) sc = scale(++X);
+    if (!(sc >= 1e5 && sc < 1e6)) return (size_t)std::snprintf(o, 32, "%g", v);
+    const double fl = std::floor(sc), frac = sc - fl;
+    if (std::fabs(frac - 0.5) < 1e-6) return (size_t)std::snprintf(o, 32, "%g", v);  // too close to call: let printf decide
+    uint32_t n = (uint32_t)fl + (frac > 0.5 ? 1u : 0u);
+    if (n == 1000000u) { n = 100000u; ++X; }
+    char d[6];
+    for (int k = 5; k >= 0; --k) { d[k] = (char)('0' + n % 10); n /= 10; }
+    int nd = 6;
+    while (nd > 1 && d[nd - 1] == '0') --nd;  // %g drops trailing zeros
+    if (std::signbit(v)) *p++ = '-';
+    if (X < -4 || X >= 6) {  // d.ddddde+XX
+        *p++ = d[0];
+        if (nd > 1) { *p++ = '.'; for (int k = 1; k < nd; ++k) *p++ = d[k]; }
+        *p++ = 'e';
+        int ex = X;
+        if (ex < 0) { *p++ = '-'; ex = -ex; } else *p++ = '+';
+        if (ex < 10) *p++ = '0';
+        p = put_u32(p, (uint32_t)ex);
+    } else if (X >= 0) {  // ddd.ddd
+        for (int k = 0; k <= X; ++k) *p++ = k < nd ? d[k] : '0';
+        if (nd > X + 1) { *p++ = '.'; for (int k = X + 1; k < nd; ++k) *p++ = d[k]; }
+    } else {  // 0.000ddd
+        *p++ = '0'; *p++ = '.';
+        for (int k = 0; k < -X - 1; ++k) *p++ = '0';
+        for (int k = 0; k < nd; ++k) *p++ = d[k];
+    }
+    return (size_t)(p - o);
+}
+// one TSV row: chromosome name, then unsigned columns and one %g column at position `g_at` (0-based among the numbers)
+inline size_t put_row(char *o, const std::string &chr, std::initializer_list<uint32_t> before, double g, std::initializer_list<uint32_t> after) {
+    char *p = o;
+    std::memcpy(p, chr.data(), chr.size());
+    p += chr.size();
+    for (uint32_t u : before) { *p++ = '\t'; p = put_u32(p, u); }
+    *p++ = '\t';
+    p += fmt_g6(g, p);
+    for (uint32_t u : after) { *p++ = '\t'; p = put_u32(p, u); }
+    *p++ = '\n';
+    return (size_t)(p - o);
+}
 
 // ---- TSV writer -----------------------------------------------------------------------------
 // With -winsize 1 -stepsize 1 style runs (dxyWindow.cpp:47) the number of rows approaches the

@@ -2,9 +2,12 @@
 // by tests/test_sanitizers.py:
 //   1. to_f64 against strtod (the conversion behind the reference's operator>>) on random and hand-picked
 //      tokens: whatever it accepts has strtod's bits;
+//   1b. fmt_g6 (the hosts' TSV number formatting) against snprintf("%g") on random bit patterns, short decimals,
+//       values at and next to rounding boundaries and powers of ten: the same bytes;
 //   2. parse_table on a generated table, single- and multi-chunk;
 //   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused.
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +20,7 @@
 using namespace pgthost;
 
 static int fails = 0;
+static const double kPow10Check[20] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19};
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
 
 static void check_token(const std::string &s) {
@@ -57,6 +61,50 @@ int main(int argc, char **argv) {
         }
         if (rng() % 50 == 0) s += (char)("xe.-+ "[rng() % 6]);
         check_token(s);
+    }
+
+    // ---- fmt_g6 == printf("%g") ------------------------------------------------------------------
+    {
+        auto same = [&](double v) {
+            char a[40], b[40];
+            const size_t la = fmt_g6(v, a);
+            const int lb = std::snprintf(b, sizeof b, "%g", v);
+            if ((int)la != lb || std::memcmp(a, b, la) != 0) {
+                a[la] = 0;
+                std::fprintf(stderr, "fmt_g6 differs on %.17g: '%s' vs '%s'\n", v, a, b);
+                ++fails;
+            }
+        };
+        for (double v : {0.0, -0.0, 1.0, -1.0, 0.5, 0.1, 100000.0, 999999.0, 999999.5, 999999.4999999999, 1e6, 1e-4, 0.0001, 0.00009999995,
+                         0.000099999949999, 1e-5, 123456.5, 123456.49999999999, 123457.5, 0.0900737, -4e-05, 1.25e+06, 8.1e-15, 1e22, 1e23,
+                         1e-17, 9.9e-18, 1e27, 9.99999e26, 5e-324, 1.7976931348623157e308, 2.5, 3.5, 0.000123456, 1234.56789, 99999.95,
+                         9.999995, 9.9999949999999, 0.3333333333333333, 2.0 / 3.0, 1e5 + 0.5, 12345.65, 1.000005, 1.0000049999999999})
+            same(v), same(-v);
+        same(std::nan("")); same(HUGE_VAL); same(-HUGE_VAL);
+        for (long i = 0; i < 4 * n; ++i) {
+            const int kind = (int)(rng() % 6);
+            double v;
+            if (kind == 0) {  // random bit pattern in a sane exponent range
+                uint64_t bits = rng();
+                bits = (bits & ~(0x7FFull << 52)) | ((uint64_t)(1023 - 70 + rng() % 140) << 52);
+                std::memcpy(&v, &bits, 8);
+            } else if (kind == 1) {  // short decimals
+                v = (double)(int64_t)(rng() % 20000000 - 10000000) / kPow10Check[rng() % 10];
+            } else if (kind == 2) {  // next to a rounding boundary of the sixth digit
+                const double base = (double)(100000 + rng() % 900000) + 0.5;
+                v = std::nextafter(base, (rng() % 2) ? 0.0 : 1e9);
+                for (int k = (int)(rng() % 3); k > 0; --k) v = std::nextafter(v, (rng() % 2) ? 0.0 : 1e9);
+                v *= kPow10Check[rng() % 10] / kPow10Check[rng() % 20];
+            } else if (kind == 3) {  // ratios, as the window statistics are
+                v = ((double)(rng() % 1000000) - 300000.0) / (double)(1 + rng() % 3000000);
+            } else if (kind == 4) {  // around powers of ten
+                v = kPow10Check[rng() % 20] / kPow10Check[rng() % 20];
+                for (int k = (int)(rng() % 4); k > 0; --k) v = std::nextafter(v, (rng() % 2) ? 0.0 : 1e300);
+            } else {
+                v = (double)(rng() % 4000000000ull);
+            }
+            same(v);
+        }
     }
 
     // ---- parse_table + ColumnCache round trip --------------------------------------------------
