@@ -247,6 +247,10 @@ int pgt_plan_shards(const pgt_win *win, uint64_t n_win, uint32_t n_ranks, pgt_sh
  *   read    rank 0: device -> host copy of the assembled rows, ordered after `stream` */
 #define PGT_IPC_HANDLE_BYTES 64
 typedef struct { unsigned char opaque[PGT_IPC_HANDLE_BYTES]; } pgt_ipc_handle;
+/* PGT_OK when ctx's device can address memory of HIP device `peer_device` (peer access is enabled as a side
+ * effect); every rank checks this against the creating rank's device before it opens the buffer and falls
+ * back to a gather otherwise.  peer_device == ctx's own device is always OK. */
+int pgt_peer_access(pgt_ctx *ctx, int peer_device);
 int pgt_rowbuf_create(pgt_ctx *ctx, size_t bytes, void **dev_ptr, pgt_ipc_handle *handle);
 int pgt_rowbuf_open(pgt_ctx *ctx, const pgt_ipc_handle *handle, void **dev_ptr);
 int pgt_rowbuf_close(pgt_ctx *ctx, void *dev_ptr, int owner);

@@ -44,7 +44,7 @@ SYMBOLS = [
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
-    "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
+    "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
     "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
 ]
 PGT_TOK_CHR, PGT_TOK_SKIP, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_FREQ = range(7)
@@ -107,6 +107,7 @@ def load() -> C.CDLL:
     lib.pgt_set_profiling.argtypes = [vp, i32]
     lib.pgt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.pgt_plan_shards.argtypes = [vp, u64, u32, vp]
+    lib.pgt_peer_access.argtypes = [vp, i32]
     lib.pgt_rowbuf_create.argtypes = [vp, sz, C.POINTER(vp), vp]
     lib.pgt_rowbuf_open.argtypes = [vp, vp, C.POINTER(vp)]
     lib.pgt_rowbuf_close.argtypes = [vp, vp, i32]

@@ -349,6 +349,20 @@ int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *t
 
 static_assert(sizeof(hipIpcMemHandle_t) == PGT_IPC_HANDLE_BYTES, "pgt_ipc_handle must hold a hipIpcMemHandle_t");
 
+int pgt_peer_access(pgt_ctx *ctx, int peer_device) {
+    PGT_USE_DEVICE(ctx);
+    if (peer_device == ctx->device) return PGT_OK;
+    int can = 0;
+    if (int rc = hip_check(ctx, hipDeviceCanAccessPeer(&can, ctx->device, peer_device), "hipDeviceCanAccessPeer")) return rc;
+    if (!can) return ctx_fail(ctx, PGT_EDEVICE, "pgt_peer_access: no peer access between the two devices");
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        return PGT_OK;
+    }
+    return hip_check(ctx, e, "hipDeviceEnablePeerAccess");
+}
+
 int pgt_rowbuf_create(pgt_ctx *ctx, size_t bytes, void **dev_ptr, pgt_ipc_handle *handle) {
     PGT_USE_DEVICE(ctx);
     if (!dev_ptr || !handle) return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_create: NULL argument");

@@ -175,7 +175,7 @@ class RowExchange:
         elif self.rank == self.dst:
             try:
                 self.buf, handle = self.ctx.rowbuf_create(self.total)
-                box[0] = handle
+                box[0] = (handle, self.ctx.device)  # the other ranks check peer access to this device first
             except PgtError as e:
                 self.peer_error, ok = str(e), 0
         dist.broadcast_object_list(box, src=gdst, group=self.group)
@@ -184,7 +184,8 @@ class RowExchange:
                 ok = 0
             else:
                 try:
-                    self.buf = self.ctx.rowbuf_open(box[0], self.total)
+                    self.ctx.peer_access(box[0][1])
+                    self.buf = self.ctx.rowbuf_open(box[0][0], self.total)
                 except PgtError as e:
                     self.peer_error, ok = str(e), 0
         flag = torch.tensor([ok], dtype=torch.int32, device=self.coll_device)

@@ -178,6 +178,10 @@ class Context:
         self._ctx = self._lib.pgt_open(device)
         if not self._ctx:
             raise PgtError(_lib.PGT_EDEVICE, _lib.last_error(None))
+        if device < 0:  # "the current device": ask the runtime which one that was
+            import torch
+            device = torch.cuda.current_device()
+        self.device = int(device)
 
     def close(self):
         if self._ctx:
@@ -303,6 +307,10 @@ class Context:
         handle = (C.c_ubyte * 64)()
         self._check(self._lib.pgt_rowbuf_create(self._ctx, int(nbytes), C.byref(ptr), handle))
         return RowBuffer(ptr.value, nbytes), bytes(handle)
+
+    def peer_access(self, peer_device: int):
+        """Raises PgtError unless this context's GPU can address memory of HIP device `peer_device`."""
+        self._check(self._lib.pgt_peer_access(self._ctx, int(peer_device)))
 
     def rowbuf_open(self, handle: bytes, nbytes: int) -> RowBuffer:
         ptr = C.c_void_p(0)
