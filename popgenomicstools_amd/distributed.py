@@ -134,8 +134,8 @@ class RowExchange:
         self.torch, self.dist, self.ctx = torch, dist, ctx
         self.counts = [int(c) for c in counts]
         self.row_bytes, self.dst, self.group, self.tables = int(row_bytes), dst, group, int(tables)
-        self.device = device
-        self.coll_device = coll_device if coll_device is not None else device
+        self.device = torch.device(device)
+        self.coll_device = torch.device(coll_device) if coll_device is not None else self.device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.my_bytes = self.counts[self.rank] * self.row_bytes
@@ -178,7 +178,10 @@ class RowExchange:
                 box[0] = (handle, self.ctx.device)  # the other ranks check peer access to this device first
             except PgtError as e:
                 self.peer_error, ok = str(e), 0
-        dist.broadcast_object_list(box, src=gdst, group=self.group)
+        # nccl moves the pickled handle through a tensor on `device`: name this rank's own GPU rather than
+        # rely on the process-wide current device
+        dist.broadcast_object_list(box, src=gdst, group=self.group,
+                                   device=self.coll_device if self.coll_device.type == "cuda" else None)
         if self.rank != self.dst and ok:
             if box[0] is None:
                 ok = 0
