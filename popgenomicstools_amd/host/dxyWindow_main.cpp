@@ -98,7 +98,8 @@ static void fetch_columns(pgt_ctx *ctx, Maf &m) {
 
 // error: a message instead of an exit, so that the caller reports Pop1's problems before Pop2's whichever thread
 // met its problem first
-static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache, std::string &error) {
+// opened: the file's text when the caller has it already (NULL: open it here)
+static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &cache, std::string &error, const Text *opened = nullptr) {
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(int32_t)}};
     if (cache.load(m.n, m.runs, cols)) {  // only with PGT_COLUMN_CACHE=<dir>; plain (not gzipped-by-name-only) regular files
         m.pos.borrow(static_cast<uint32_t *>(cols[0].data));
@@ -106,11 +107,12 @@ static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &c
         m.nind.borrow(static_cast<int32_t *>(cols[2].data));
         return;
     }
-    Text text;
-    if (!text.open(path)) {
+    Text own;
+    if (!opened && !own.open(path)) {
         error = std::string("Unable to open ") + which + " MAF file: " + path;
         return;
     }
+    const Text &text = opened ? *opened : own;
     Cursor hdr{text.begin(), text.end()};
     hdr.next_line();  // header (dxyWindow.cpp:284)
     m.n = parse_table(hdr.p, text.end(), m, m.runs, kMafWhat, path, 2, &error);
@@ -167,9 +169,19 @@ int main(int argc, char **argv) {
     Maf m1, m2;
     ColumnCache c1("dxyWindow maf", argv[argc - 2]), c2("dxyWindow maf", argv[argc - 1]);  // own the mappings the columns may borrow
     bool parsed = false;
-    if (!c1.enabled()) {  // large inputs: parse both files on the GPU, one after the other (one context, one thread)
-        Text t1, t2;  // a file that cannot be opened is left to the host path below, which reports Pop1's problems first
-        if (t1.open(argv[argc - 2]) && t2.open(argv[argc - 1]) && gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
+    // Without the column cache both texts are opened here, side by side (a one-member .gz inflates on one thread,
+    // a bgzf file on all of them), and serve whichever parser runs.  They are never unmapped or freed: giving
+    // back gigabytes of text costs more than everything downstream of the parse, and the process ends by _exit.
+    Text &t1 = *new Text, &t2 = *new Text;
+    bool open1 = false, open2 = false;
+    if (!c1.enabled()) {
+        std::thread other([&] { open1 = t1.open(argv[argc - 2]); });
+        open2 = t2.open(argv[argc - 1]);
+        other.join();
+        timer.lap("open");
+        // large inputs: parse both files on the GPU, one after the other (one context, one thread); a file that
+        // cannot be opened is left to the host path below, which reports Pop1's problems first
+        if (open1 && open2 && gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
             parsed = read_maf_on_device(c, t1, argv[argc - 2], m1) && read_maf_on_device(c, t2, argv[argc - 1], m2);
@@ -179,9 +191,9 @@ int main(int argc, char **argv) {
     }
     if (!parsed) {  // the two files are independent: parse them side by side on the host
         std::string e1, e2;
-        std::thread t1([&] { read_maf(argv[argc - 2], "Pop1", m1, c1, e1); });
-        read_maf(argv[argc - 1], "Pop2", m2, c2, e2);
-        t1.join();
+        std::thread th([&] { read_maf(argv[argc - 2], "Pop1", m1, c1, e1, open1 ? &t1 : nullptr); });
+        read_maf(argv[argc - 1], "Pop2", m2, c2, e2, open2 ? &t2 : nullptr);
+        th.join();
         if (!e1.empty()) die(e1);
         if (!e2.empty()) die(e2);
         timer.lap("parse");

@@ -123,8 +123,12 @@ class Text {
         unsigned char magic[2] = {0, 0};
         const ssize_t got = pread(fd, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            const int r = st.st_size >= 28 ? inflate_bgzf(fd, (size_t)st.st_size) : 0;
+            unsigned char tail[4] = {0, 0, 0, 0};  // ISIZE of the (last) member: the text's size when there is one member < 4 GiB
+            if (!r && st.st_size >= 18 && pread(fd, tail, 4, st.st_size - 4) != 4) std::memset(tail, 0, 4);
             ::close(fd);
-            return slurp(path);
+            const size_t isize = (size_t)tail[0] | (size_t)tail[1] << 8 | (size_t)tail[2] << 16 | (size_t)tail[3] << 24;
+            return r ? r > 0 : slurp(path, std::max(isize, (size_t)st.st_size));
         }
         if (st.st_size == 0) {
             ::close(fd);
@@ -173,14 +177,90 @@ class Text {
         }
         for (auto &x : th) x.join();
     }
-    bool slurp(const char *path) {
+    // ANGSD writes its .mafs.gz through bgzf: a series of independent gzip members of at most 64 KiB of text,
+    // each announcing its own compressed size in a "BC" extra field.  Such a file is inflated block-parallel
+    // (zlib's raw inflate per member, CRC-32 and length checked as gzread would); the text is the same bytes
+    // the reference's gzip_decompressor (dxyWindow.cpp:256-278) or gzread produce from the same file.
+    // -> 1 done, -1 a member is damaged (the input cannot be read), 0 not bgzf from the first byte to the
+    // last: nothing was done, the caller reads the file through gzread (any gzip stream, trailing garbage
+    // ignored as zlib does).
+    int inflate_bgzf(int fd, size_t zlen) {
+        struct Member { size_t data, data_len, out; uint32_t crc, isize; };
+        void *zmap = mmap(nullptr, zlen, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (zmap == MAP_FAILED) return 0;
+        const unsigned char *z = static_cast<const unsigned char *>(zmap);
+        auto u16 = [&](size_t o) { return (size_t)z[o] | (size_t)z[o + 1] << 8; };
+        auto u32 = [&](size_t o) { return (uint32_t)z[o] | (uint32_t)z[o + 1] << 8 | (uint32_t)z[o + 2] << 16 | (uint32_t)z[o + 3] << 24; };
+        std::vector<Member> mem;
+        size_t off = 0, total = 0;
+        bool bgzf = true;
+        while (bgzf && off < zlen) {
+            bgzf = false;
+            if (zlen - off < 26 || z[off] != 0x1f || z[off + 1] != 0x8b || z[off + 2] != 8 || z[off + 3] != 4) break;  // FLG = FEXTRA only
+            const size_t xlen = u16(off + 10), hdr = 12 + xlen;
+            if (hdr + 8 > zlen - off) break;
+            size_t bsize = 0;
+            for (size_t x = off + 12; x + 4 <= off + hdr;) {  // subfields: SI1 SI2 SLEN data
+                const size_t slen = u16(x + 2);
+                if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2 && x + 6 <= off + hdr) bsize = u16(x + 4) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < hdr + 8 || bsize > zlen - off) break;
+            const uint32_t isize = u32(off + bsize - 4);
+            if (isize > (1u << 16)) break;
+            mem.push_back(Member{off + hdr, bsize - hdr - 8, total, u32(off + bsize - 8), isize});
+            total += isize;
+            off += bsize;
+            bgzf = true;
+        }
+        if (!bgzf || mem.empty()) {
+            munmap(zmap, zlen);
+            return 0;
+        }
+        big_.reset(new char[total ? total : 1]);  // not value-initialised: the inflating threads touch the pages first
+        unsigned T = std::thread::hardware_concurrency();
+        T = T ? (T > 32 ? 32 : T) : 1;
+        if (const char *e = std::getenv("PGT_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
+        T = (unsigned)std::min<size_t>(T, (mem.size() + 63) / 64);
+        std::vector<char> bad(T, 0);
+        std::vector<std::thread> th;
+        char *out = big_.get();
+        for (unsigned t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                z_stream zs{};
+                if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+                for (size_t i = mem.size() * t / T, e = mem.size() * (t + 1) / T; i < e && !bad[t]; ++i) {
+                    const Member &m = mem[i];
+                    zs.next_in = const_cast<unsigned char *>(z + m.data);
+                    zs.avail_in = (uInt)m.data_len;
+                    zs.next_out = reinterpret_cast<unsigned char *>(out + m.out);
+                    zs.avail_out = m.isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    if (rc != Z_STREAM_END || zs.avail_out != 0 || zs.avail_in != 0 ||
+                        (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(out + m.out), m.isize) != m.crc)
+                        bad[t] = 1;
+                    inflateReset(&zs);
+                }
+                inflateEnd(&zs);
+            });
+        for (auto &x : th) x.join();
+        munmap(zmap, zlen);
+        if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return -1;
+        b_ = big_.get();
+        e_ = b_ + total;
+        return 1;
+    }
+    bool slurp(const char *path, size_t expect = 0) {
         gzFile f = gzopen(path, "rb");
         if (!f) return false;
+        if (expect) own_.reserve(expect + 1);  // a hint: no regrowth copies when it is right
         gzbuffer(f, 1 << 20);
         std::vector<char> buf(1 << 22);
         int n;
         while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) own_.append(buf.data(), (size_t)n);
-        const bool ok = n == 0;
+        int zerr = Z_OK;
+        (void)gzerror(f, &zerr);  // a file cut inside a member reads as a short stream: gzread returns 0, the error says so
+        const bool ok = n == 0 && (zerr == Z_OK || zerr == Z_STREAM_END);
         gzclose(f);
         b_ = own_.data();
         e_ = b_ + own_.size();
@@ -189,6 +269,7 @@ class Text {
     void *map_ = nullptr;
     size_t map_len_ = 0;
     std::string own_;
+    std::unique_ptr<char[]> big_;  // text inflated from a bgzf file
     const char *b_ = "", *e_ = b_;
 };
 

@@ -24,6 +24,39 @@ def wall(cmd, env=None):
     return time.perf_counter() - t, r
 
 
+def bgzf_copy(src, dst, block=0xff00):
+    """src as a bgzf file (members of <= 64 KiB with the BC size field + the empty end member); 8 threads (zlib drops the GIL)"""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def member(c):
+        z = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = z.compress(c) + z.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(d) + 8 - 1) + d +
+                struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+    with open(src, "rb") as fi, open(dst, "wb") as fo, ThreadPoolExecutor(8) as ex:
+        while True:
+            big = fi.read(block * 2048)
+            if not big:
+                break
+            for m in ex.map(member, [big[o: o + block] for o in range(0, len(big), block)]):
+                fo.write(m)
+        fo.write(member(b""))
+
+
+def gzip_copy(src, dst):
+    import zlib
+    z = zlib.compressobj(6, zlib.DEFLATED, 31)
+    with open(src, "rb") as fi, open(dst, "wb") as fo:
+        while True:
+            big = fi.read(1 << 24)
+            if not big:
+                break
+            fo.write(z.compress(big))
+        fo.write(z.flush())
+
+
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
     orc = oracle_bind.load()
@@ -102,6 +135,22 @@ def main():
               f"{same} (ints exact, sums to 6 digits) | {phases} |")
         os.unlink(o_out)
         os.unlink(o_err)
+    # the same MAF pair gzipped: as bgzf (what ANGSD writes; inflated block-parallel) and as ordinary one-member gzip (gzread)
+    opts = ["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-fixedsite", "1"]
+    _, r_plain = wall([os.path.join(BIN, "dxyWindow")] + opts + [f_m1, f_m2])
+    for label, writer in (("bgzf", bgzf_copy), ("one-member gzip", gzip_copy)):
+        z1, z2 = f_m1 + ".gz", f_m2 + ".gz"
+        writer(f_m1, z1)
+        writer(f_m2, z2)
+        env = dict(os.environ, PGT_HOST_TIMING="1")
+        cmd = [os.path.join(BIN, "dxyWindow")] + opts + [z1, z2]
+        wall(cmd, env)
+        t_new, r_new = wall(cmd, env)
+        phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
+        print(f"| dxyWindow -fixedsite 1, both inputs {label} ({os.path.getsize(z1) / 1e6:.0f} + {os.path.getsize(z2) / 1e6:.0f} MB) | n/a | {t_new:.2f} | | "
+              f"{len(r_new.stdout.splitlines())} | {r_new.stdout == r_plain.stdout} (vs the plain-text run) | {phases} |")
+        os.unlink(z1)
+        os.unlink(z2)
     for p_ in (f_m1, f_m2, f_sz):
         os.unlink(p_)
     chr_ids, pos = full

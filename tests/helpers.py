@@ -83,3 +83,19 @@ def extreme_case_args(case, tmp_path):
     chrlen = paths[a[a.index("-chrlen") + 1][1:]] if "-chrlen" in a else None
     cutoff = float(a[a.index("-cutoff") + 1]) if case["tool"] == "ihsWindow" else float(a[1])
     return paths["in.norm"], W, cutoff, chrlen
+
+
+def write_bgzf(path, data: bytes, block=0xff00, level=6):
+    """`data` as a bgzf file (what ANGSD writes its .mafs.gz with): independent gzip members of at most 64 KiB,
+    each with the "BC" extra field giving its size, then the empty end-of-file member."""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[o: o + block] for o in range(0, len(data), block)] + [b""]
+    for c in chunks:
+        z = zlib.compressobj(level, zlib.DEFLATED, -15)
+        d = z.compress(c) + z.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(d) + 8 - 1)
+        out += d + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c))
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))

@@ -5,7 +5,9 @@
 //   1b. fmt_g6 (the hosts' TSV number formatting) against snprintf("%g") on random bit patterns, short decimals,
 //       values at and next to rounding boundaries and powers of ten: the same bytes;
 //   2. parse_table on a generated table, single- and multi-chunk;
-//   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused.
+//   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused;
+//   4. Text on gzip input: a bgzf file (block-parallel inflate), a plain gzip file and a bgzf file followed by a
+//      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused.
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -33,6 +35,38 @@ static void check_token(const std::string &s) {
         const double c = std::strtod(start, &end);
         if (*end == 0 && std::memcmp(&a, &c, 8) != 0) { std::fprintf(stderr, "strtod differs on '%s'\n", s.c_str()); ++fails; }
     }
+}
+
+// one bgzf member (SAM spec 4.1): gzip header with the "BC" extra field, raw deflate data, CRC-32, length
+static std::string bgzf_member(const char *p, size_t n) {
+    std::vector<unsigned char> def(compressBound(n) + 64);
+    z_stream zs{};
+    deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = reinterpret_cast<unsigned char *>(const_cast<char *>(p));
+    zs.avail_in = (uInt)n;
+    zs.next_out = def.data();
+    zs.avail_out = (uInt)def.size();
+    deflate(&zs, Z_FINISH);
+    const size_t dn = def.size() - zs.avail_out;
+    deflateEnd(&zs);
+    const size_t bsize = 18 + dn + 8;
+    std::string m("\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0", 16);
+    m += (char)((bsize - 1) & 0xff);
+    m += (char)((bsize - 1) >> 8);
+    m.append(reinterpret_cast<char *>(def.data()), dn);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(p), (uInt)n), len = (uint32_t)n;
+    for (int k = 0; k < 4; ++k) m += (char)(crc >> (8 * k));
+    for (int k = 0; k < 4; ++k) m += (char)(len >> (8 * k));
+    return m;
+}
+static void put_file(const std::string &path, const std::string &bytes) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    std::fwrite(bytes.data(), 1, bytes.size(), f);
+    std::fclose(f);
+}
+static bool text_is(const std::string &path, const std::string &want) {
+    Text t;
+    return t.open(path.c_str()) && t.size() == want.size() && std::memcmp(t.begin(), want.data(), want.size()) == 0;
 }
 
 int main(int argc, char **argv) {
@@ -181,6 +215,57 @@ int main(int argc, char **argv) {
             CHECK(!other.load(n2, r2, b2));
             std::remove(input.c_str());
         }
+    }
+    {   // 4. gzip input
+        const std::string dir = argc > 3 ? argv[3] : "/tmp";
+        std::string text;
+        for (long i = 0; i < 60000; ++i) text += "chr" + std::to_string(i / 9000) + "\t" + std::to_string(i * 7 + 1) + "\t0." + std::to_string(100000 + rng() % 900000) + "\n";
+        std::string bg;
+        std::vector<size_t> starts;
+        for (size_t o = 0; o < text.size();) {
+            const size_t n = std::min<size_t>(text.size() - o, 500 + rng() % (o % 3 ? 4000 : 64000));  // ragged blocks, all <= 64 KiB
+            starts.push_back(bg.size());
+            bg += bgzf_member(text.data() + o, n);
+            o += n;
+        }
+        const std::string eof = bgzf_member("", 0);  // the empty member bgzf files end with
+        for (int threads : {1, 5}) {
+            setenv("PGT_HOST_THREADS", std::to_string(threads).c_str(), 1);
+            put_file(dir + "/t.bgzf.gz", bg + eof);
+            CHECK(text_is(dir + "/t.bgzf.gz", text));
+            put_file(dir + "/t.bgzf.gz", bg);  // no end marker: still complete members
+            CHECK(text_is(dir + "/t.bgzf.gz", text));
+        }
+        CHECK(starts.size() > 64);
+        {
+            gzFile g = gzopen((dir + "/t.plain.gz").c_str(), "wb");
+            gzwrite(g, text.data(), (unsigned)text.size());
+            gzclose(g);
+            CHECK(text_is(dir + "/t.plain.gz", text));
+            // bgzf members followed by an ordinary gzip member: not bgzf to the end -> gzread, which reads all members
+            FILE *f = std::fopen((dir + "/t.plain.gz").c_str(), "rb");
+            std::string plain(1 << 22, 0);
+            plain.resize(std::fread(&plain[0], 1, plain.size(), f));
+            std::fclose(f);
+            put_file(dir + "/t.mixed.gz", bg + plain);
+            CHECK(text_is(dir + "/t.mixed.gz", text + text));
+        }
+        {
+            std::string hurt = bg + eof;
+            hurt[starts[starts.size() / 2] + 40] ^= 0x55;  // inside the deflate data of a middle block
+            put_file(dir + "/t.hurt.gz", hurt);
+            Text t;
+            CHECK(!t.open((dir + "/t.hurt.gz").c_str()));
+            std::string crc = bg + eof;
+            crc[starts[3] - 6] ^= 1;  // the CRC-32 of block 2
+            put_file(dir + "/t.hurt.gz", crc);
+            Text t2;
+            CHECK(!t2.open((dir + "/t.hurt.gz").c_str()));
+            put_file(dir + "/t.hurt.gz", bg.substr(0, starts[5] + 100));  // cut inside block 5
+            Text t3;
+            CHECK(!t3.open((dir + "/t.hurt.gz").c_str()));
+        }
+        for (const char *n : {"/t.bgzf.gz", "/t.plain.gz", "/t.mixed.gz", "/t.hurt.gz"}) std::remove((dir + n).c_str());
     }
     std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);
     return fails ? 1 : 0;

@@ -271,6 +271,11 @@ def test_cli_input_format_edge_cases(hosts, tmp_path):
     with gzip.open(gz, "wt") as fh:
         fh.write(plain)
     assert run([hosts["fstWindow"], str(gz), "4", "2"]).stdout == ref.stdout
+    # ... and so is bgzf (ANGSD's gzip flavour: inflated block-parallel), with blocks cut inside lines
+    bg = tmp_path / "plain.bgzf.gz"
+    helpers.write_bgzf(bg, plain.encode(), block=37)
+    assert gzip.open(bg, "rb").read() == plain.encode()  # the file is a valid multi-member gzip file
+    assert run([hosts["fstWindow"], str(bg), "4", "2"]).stdout == ref.stdout
 
 
 # ---- binary column cache (PGT_COLUMN_CACHE) ----------------------------------------------
