@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     // is node writes interleaved with the read stream, here 3.5 % of the bytes.  (Round 2, tried and dropped:
     // requesting the next level-2 tile's first leaf BEFORE the block is stored, so that no load queues
     // behind 18 KiB of stores in the in-order vmcnt: 69.6 % vs 71.2 % without, 230 VGPRs instead of 188,
-    // profiles/r02/af_pipe.txt.)
+    // profiles/r02/af_pipe.txt.  Also dropped: TWO level-2 tiles staged per flush (36-KiB bursts, 144 KiB of LDS
+    // per workgroup) and/or three leaves prefetched instead of one (32 loads in flight per lane, 1 wave per
+    // SIMD): 67.9-69.9 % against 69.7 % in the same session, rows identical — profiles/r02/af_stage2.txt.)
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
     double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kWave;
 
