@@ -210,3 +210,35 @@ def test_absurdly_long_lines_are_refused_not_walked(ctx):
     assert e.value.code == _lib.PGT_EDOMAIN
     ok = b"c1\t1\t0.1\t0.2\n" + b"c1\t2\t0.5\t0.2 " + b"x" * 60_000 + b"\nc1\t3\t0.1\t0.2\n"  # long but under the cap: extra columns
     assert check(ctx, ok, FST) == 3
+
+
+def test_text_beyond_4_gib(ctx):
+    """Maximum sizes: 4.6 GB of text (byte offsets, run-name offsets and block counts beyond 2^32): a 10^6-line
+    block with two chromosome names, repeated 160 times with a few irregular lines (slow path) in every block."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20e9:
+        pytest.skip("needs ~12 GB of free HBM")
+    rng = np.random.default_rng(8)
+    m = 1_000_000
+    pos = np.arange(1, m + 1, dtype=np.uint32)
+    a = np.round(rng.uniform(-0.1, 0.6, m), 6)
+    b = np.round(rng.uniform(0.0, 0.3, m), 6)
+    lines = [b"chrA\t%d\t%.6f\t%.6f\n" % (p, x, y) if i < m // 2 else b"chrBB\t%d\t%.6f\t%.6f\n" % (p, x, y)
+             for i, (p, x, y) in enumerate(zip(pos, a, b))]
+    for i in (17, 500_003, 999_999):  # irregular lines: 17 significant digits, exponent form, a '+' sign
+        lines[i] = lines[i].split(b"\t")[0] + b"\t%d\t0.12345678901234567\t+2.5e-1\n" % pos[i]
+        a[i], b[i] = 0.12345678901234567, 0.25
+    block = b"".join(lines)
+    reps = 160
+    text = block * reps
+    assert len(text) > (1 << 32) + (1 << 28)
+    ing = ctx.ingest_text(text, FST)
+    assert ing.bad_line == -1 and ing.rows == m * reps
+    assert ing.run_names == ["chrA", "chrBB"] * reps
+    assert np.array_equal(ing.run_len, np.full(2 * reps, m // 2, dtype=np.uint64))
+    for k, want in ((1, pos), (2, a), (3, b)):
+        got = ing.column_np(k).reshape(reps, m)
+        assert np.array_equal(got[0].view(np.uint8), want.view(np.uint8))       # the bits of the first block
+        assert (got == got[0]).all()                                            # ... and of every repeat
+    ing.free()
