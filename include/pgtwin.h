@@ -294,7 +294,7 @@ int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, 
 int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2,
                         const int32_t *d_n1, const int32_t *d_n2, uint64_t n, int minind,
                         const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot);
-/* device column of token `token` -> host (bytes = rows * element size) */
+/* device column of token `token` -> host (bytes <= rows * element size, else PGT_EARG) */
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
 uint64_t pgt_ingest_rows(const pgt_ingest *ing);

@@ -540,6 +540,7 @@ int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *ho
     void *src = pgt_ingest_column(ing, token);
     if (bytes == 0) return PGT_OK;
     if (!src || !host_dst) return ctx_fail(ctx, PGT_EARG, "pgt_ingest_download: no such column");
+    if (bytes > ingest_column_bytes(ing, token)) return ctx_fail(ctx, PGT_EARG, "pgt_ingest_download: more bytes than the column holds");
     return hip_check(ctx, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost), "pgt_ingest_download");
 }
 

@@ -542,6 +542,11 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     return PGT_OK;
 }
 
+size_t ingest_column_bytes(const pgt_ingest *g, int token) {
+    if (!g || token < 0 || token >= g->n_tokens || !g->col[token]) return 0;
+    return (size_t)g->rows * elem_bytes(g->tok[token]);
+}
+
 }  // namespace pgt
 
 extern "C" {

@@ -148,6 +148,7 @@ int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *
 
 // pgt_ingest.hip: text -> device columns + chromosome runs (synchronous, default stream of `device`)
 int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err);
+size_t ingest_column_bytes(const pgt_ingest *ing, int token);  // rows * element size of the token's column (0: no column)
 
 int init_kernels(std::string *err);     // pgt_kernels.hip: one-time kernel attributes (called by pgt_open)
 int init_af_kernels(std::string *err);  // pgt_af_kernels.hip

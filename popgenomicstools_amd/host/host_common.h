@@ -477,7 +477,8 @@ class ColumnCache {
         ::close(fd);
         if (map_ == MAP_FAILED) { map_ = nullptr; return false; }
         const char *b = static_cast<const char *>(map_), *e = b + map_len_, *p = b;
-        auto u64 = [&](uint64_t &v) { if (p + 8 > e) return false; std::memcpy(&v, p, 8); p += 8; return true; };
+        auto room = [&](uint64_t bytes) { return bytes <= (uint64_t)(e - p); };  // sizes are compared, never added to pointers
+        auto u64 = [&](uint64_t &v) { if (!room(8)) return false; std::memcpy(&v, p, 8); p += 8; return true; };
         uint64_t n = 0, n_runs = 0, n_cols = 0;
         if (std::memcmp(p, "PGTCOLS1", 8) != 0) return false;
         p += 8;
@@ -485,16 +486,17 @@ class ColumnCache {
         Runs r;
         for (uint64_t k = 0; k < n_runs; ++k) {
             uint64_t len = 0, nb = 0;
-            if (!u64(len) || !u64(nb) || p + ((nb + 7) & ~7ull) > e) return false;
+            if (!u64(len) || !u64(nb) || nb > map_len_ || !room((nb + 7) & ~7ull)) return false;
             r.name.emplace_back(p, p + nb);
             r.len.push_back(len);
             p += (nb + 7) & ~7ull;
         }
         for (auto &c : cols) {
             uint64_t bytes = 0;
-            if (!u64(bytes) || bytes != n * c.elem) return false;
-            p = b + (((size_t)(p - b) + 63) & ~(size_t)63);
-            if (p + bytes > e) return false;
+            if (!u64(bytes) || n > map_len_ || bytes != n * c.elem) return false;
+            const size_t at = ((size_t)(p - b) + 63) & ~(size_t)63;
+            if (at > map_len_ || bytes > map_len_ - at) return false;
+            p = b + at;
             c.data = const_cast<char *>(p);
             p += bytes;
         }

@@ -8,6 +8,8 @@
 //   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused;
 //   4. Text on gzip input: a bgzf file (block-parallel inflate), a plain gzip file and a bgzf file followed by a
 //      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused.
+#include <dirent.h>
+
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -207,6 +209,43 @@ int main(int argc, char **argv) {
                 std::vector<ColumnCache::Col> wrong2 = {{nullptr, 8}, {nullptr, 8}, {nullptr, 8}};  // element size mismatch
                 ColumnCache c3("check", input.c_str());
                 CHECK(!c3.load(n1, r1, wrong2));
+            }
+            {   // damaged cache files: header words replaced by extreme values, the file cut at random lengths — load
+                // must refuse or return something consistent, and never read outside the mapping (ASan watches)
+                std::string cache_file;
+                if (DIR *dh = opendir(dir.c_str())) {
+                    while (dirent *de = readdir(dh)) {
+                        const std::string nm = de->d_name;
+                        if (nm.size() > 8 && nm.substr(nm.size() - 8) == ".pgtcols") cache_file = dir + "/" + nm;
+                    }
+                    closedir(dh);
+                }
+                CHECK(!cache_file.empty());
+                FILE *cf = std::fopen(cache_file.c_str(), "rb");
+                std::string good((size_t)rows * 20 + 4096, 0);
+                good.resize(std::fread(&good[0], 1, good.size(), cf));
+                std::fclose(cf);
+                const uint64_t evil[] = {~0ull, 1ull << 63, (1ull << 61) + 1, good.size(), good.size() - 7, 0ull, rows + 1, 1ull << 32};
+                for (int trial = 0; trial < 200; ++trial) {
+                    std::string bad = good;
+                    if (trial % 4 == 3) bad.resize(rng() % good.size());
+                    else {
+                        const size_t word = 8 + 8 * (rng() % 40);  // header, run table and the first column header
+                        const uint64_t v = evil[rng() % 8];
+                        if (word + 8 <= bad.size()) std::memcpy(&bad[word], &v, 8);
+                    }
+                    put_file(cache_file, bad);
+                    ColumnCache c("check", input.c_str());
+                    size_t n3 = 0;
+                    Runs r3;
+                    std::vector<ColumnCache::Col> b3 = {{nullptr, 4}, {nullptr, 8}, {nullptr, 8}};
+                    if (c.load(n3, r3, b3)) {  // accepted: every column must lie inside the file
+                        volatile unsigned char sink = 0;
+                        for (auto &col : b3)
+                            if (n3) sink = sink + static_cast<unsigned char *>(col.data)[0] + static_cast<unsigned char *>(col.data)[n3 * col.elem - 1];
+                    }
+                }
+                put_file(cache_file, good);
             }
             ColumnCache other("another tool", input.c_str());  // the tag is part of the key
             size_t n2 = 0;

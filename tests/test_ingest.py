@@ -201,6 +201,17 @@ def test_ingested_columns_feed_the_scan(pgt, ctx, oracle):
     assert C.sizeof(C.c_void_p) == 8
 
 
+def test_download_is_bounded_by_the_column(ctx):
+    import ctypes as C
+    ing = ctx.ingest_text(b"c\t1\t0.5\t0.25\nc\t2\t0.5\t0.25\n", FST)
+    lib, host = ctx._lib, np.zeros(64, dtype=np.uint8)
+    assert lib.pgt_ingest_download(ctx._ctx, ing._h, 2, host.ctypes.data, 16) == _lib.PGT_OK
+    assert host[:16].view(np.float64).tolist() == [0.5, 0.5]
+    assert lib.pgt_ingest_download(ctx._ctx, ing._h, 2, host.ctypes.data, 24) == _lib.PGT_EARG   # 2 rows of 8 bytes only
+    assert lib.pgt_ingest_download(ctx._ctx, ing._h, 0, host.ctypes.data, 8) == _lib.PGT_EARG    # the name token has no column
+    ing.free()
+
+
 def test_absurdly_long_lines_are_refused_not_walked(ctx):
     """A line of 300 KB is not one of the tools' tables: the device path refuses the input (PGT_EDOMAIN) instead
     of letting one lane walk through it; the hosts then parse it themselves."""
