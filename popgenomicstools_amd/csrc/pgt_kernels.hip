@@ -701,6 +701,11 @@ __device__ __forceinline__ void ragged_pair(typename Tr::Node &acc, const typena
 
 // Wave-wide reduction of the site range [lo,hi): every lane returns a partial (node_wave_sum of it is
 // the range's node).  The accumulation order depends on the range only, never on the window table.
+// (Round 2, tried and dropped: planning the whole descent first in scalar registers and issuing the loads
+// of ALL levels before the first addition, with the table read by scalar loads one window ahead — rows
+// bit-identical, but 0.095 instead of 0.085 ms for the 10^5 windows of the headline run and 0.76 instead of
+// 0.66 ms at S = 100: the kernel moves ~3.3 KB per window and runs at the equivalent of 6 TB/s, it is not
+// waiting on round trips, and the plan costs 27 VGPRs of occupancy.  profiles/r02/measure_query_pipelined.md)
 template <class Tr>
 __device__ __forceinline__ typename Tr::Node range_partial(const typename Tr::Cols &c, const char *tree, const TreeView &tv,
                                                            uint64_t lo, uint64_t hi, int lane, uint64_t n_sites) {

@@ -265,8 +265,7 @@ class Context:
     def tree_bytes(stat: int, n_sites: int) -> int:
         return int(_lib.load().pgt_tree_bytes(stat, n_sites))
 
-    @staticmethod
-    def _dev(t, dtype, name):
+    def _dev(self, t, dtype, name):
         import torch
         if isinstance(t, RowBuffer) and dtype == torch.uint8:
             return t.data_ptr()
@@ -274,6 +273,8 @@ class Context:
             return t.data_ptr() if t.numel() else None
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
             raise PgtError(_lib.PGT_EARG, f"{name}: expected a contiguous CUDA tensor of {dtype}")
+        if t.device.index != self.device:  # the kernels run on the context's GPU: memory of another one may not even be mapped there
+            raise PgtError(_lib.PGT_EARG, f"{name}: tensor lives on cuda:{t.device.index}, the context on cuda:{self.device}")
         return t.data_ptr() if t.numel() else None  # an empty shard passes NULL columns (n == 0)
 
     @staticmethod
