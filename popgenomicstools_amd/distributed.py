@@ -300,3 +300,82 @@ def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows
     if rank != dst:
         return None
     return np.frombuffer(packed.tobytes(), dtype=row_dtype)
+
+
+TOTAL_BLOCK = 1 << 16  # sites per block of the genome-wide dxy total (= the smallest shard alignment)
+
+
+def sharded_dxy_scan(win: np.ndarray, n_sites: int, load_columns, ctx, minind: int, device, dst: int = 0, group=None,
+                     mode: str = "gather", coll_device=None):
+    """dxyWindow over several GPUs: the window rows AND the genome-wide line (dxyWindow.cpp:382-385,429-433).
+
+    The total has to see every site once, also sites no window covers (dropped tails), so the site
+    axis is cut at the shard starts into one owned range per rank; a rank adds its owned range to its window
+    block as windows of TOTAL_BLOCK sites, the rows of those blocks travel with the window rows, and `dst` adds
+    them up in block order.  The total is therefore the same bits for every number of ranks (one rank included):
+    block starts are multiples of 2^16 on every shard, so a block's sum is always taken over the same tree
+    nodes.  It equals pgt_dxy_reduce's own total (one query over the whole tree) in neff and nskip, and in the
+    sum to rounding (different association of the same additions).
+
+      load_columns(site_lo, site_hi) -> (pos, p1, p2, n1, n2) device columns of those sites
+    Returns on dst (rows [DXY_ROW_DTYPE, one per window], total [DXY_TOTAL_DTYPE scalar]); (None, None) elsewhere.
+    """
+    import torch.distributed as dist
+    from ._lib import DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, PGT_WIN_COORDS
+    from .window_scan import windows_to_device
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    shards = plan_shards(win, world)
+    n_sites = int(n_sites)
+    # owned site ranges: cut[r] = where rank r's columns start (the next shard start for a rank without windows)
+    cut = [0] * (world + 1)
+    cut[world] = n_sites
+    for r in range(world - 1, 0, -1):
+        has = int(shards[r]["win_end"]) > int(shards[r]["win_begin"])
+        cut[r] = min(int(shards[r]["site_lo"]), cut[r + 1]) if has else cut[r + 1]
+        assert cut[r] % TOTAL_BLOCK == 0 or cut[r] == n_sites, "shard starts are multiples of 2^16 (pgt_plan_shards)"
+
+    def blocks_of(r):
+        return range(cut[r] // TOTAL_BLOCK, (cut[r + 1] + TOTAL_BLOCK - 1) // TOTAL_BLOCK) if cut[r + 1] > cut[r] else range(0)
+    n_own = [int(shards[r]["win_end"]) - int(shards[r]["win_begin"]) for r in range(world)]
+    counts = [n_own[r] + len(blocks_of(r)) for r in range(world)]
+
+    s = shards[rank]
+    lo = cut[rank]
+    hi = max(int(s["site_hi"]) if n_own[rank] else lo, cut[rank + 1])
+    local = np.zeros(counts[rank], dtype=WIN_DTYPE)
+    local[: n_own[rank]] = win[int(s["win_begin"]): int(s["win_end"])]
+    blk = local[n_own[rank]:]
+    first = np.array(list(blocks_of(rank)), dtype=np.uint64) * np.uint64(TOTAL_BLOCK)
+    blk["lo"] = first
+    blk["hi"] = np.minimum(first + np.uint64(TOTAL_BLOCK), np.uint64(cut[rank + 1]))
+    blk["flags"] = PGT_WIN_COORDS  # no coordinates to look up
+    local["lo"] -= np.uint64(lo)
+    local["hi"] -= np.uint64(lo)
+
+    ex = RowExchange(ctx, counts, DXY_ROW_DTYPE.itemsize, device, dst=dst, group=group, mode=mode, coll_device=coll_device)
+    out = ex.begin()
+    if counts[rank]:
+        pos, p1, p2, n1, n2 = load_columns(lo, hi)
+        ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, minind, windows_to_device(local, device), out=out)
+    ex.end()
+    packed = ex.finish()
+    ex.close()
+    if rank != dst:
+        return None, None
+    allrows = np.frombuffer(packed.tobytes(), dtype=DXY_ROW_DTYPE)
+    rows, blocks, at = [], [], 0
+    for r in range(world):
+        rows.append(allrows[at: at + n_own[r]])
+        blocks.append(allrows[at + n_own[r]: at + counts[r]])
+        at += counts[r]
+    rows, blocks = np.concatenate(rows), np.concatenate(blocks)
+    total = np.zeros((), dtype=DXY_TOTAL_DTYPE)
+    acc = 0.0
+    for v in blocks["sum"].tolist():  # in block order, one addition per block: the same on every rank count
+        acc += v
+    total["sum"] = acc
+    total["neff"] = int(blocks["neff"].astype(np.uint64).sum())
+    total["nskip"] = int(blocks["nskip"].astype(np.uint64).sum())
+    return rows, total

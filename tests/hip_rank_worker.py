@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import popgenomicstools_amd as pgt  # noqa: E402
-from popgenomicstools_amd._lib import EXT_ROW_DTYPE, FST_ROW_DTYPE, PGT_EXT_IHS  # noqa: E402
-from popgenomicstools_amd.distributed import sharded_scan  # noqa: E402
+from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, EXT_ROW_DTYPE, FST_ROW_DTYPE, PGT_EXT_IHS,  # noqa: E402
+                                       WIN_DTYPE)
+from popgenomicstools_amd.distributed import TOTAL_BLOCK, sharded_dxy_scan, sharded_scan  # noqa: E402
 from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
 
@@ -104,6 +105,33 @@ def main():
         assert int((ewin["hi"] - ewin["lo"]).max()) >= 1 << 20
         assert got.tobytes() == ref, "extreme"
         print("HIP_RANKS_OK extreme peer", flush=True)
+
+    # ---- dxyWindow: window rows + the genome-wide line, bits independent of the rank count ---------
+    ctx.set_max_window(W)
+
+    def dxy_cols(lo, hi):
+        return (g.pos_t(lo, hi, dev),) + tuple(g.dxy_columns_t(lo, hi, dev))
+    minind = 5
+    if rank == 0:
+        out1, tot1, _ = ctx.dxy_reduce_dev(*dxy_cols(0, n), minind, windows_to_device(win, dev))
+        ref_rows = rows_from_device(out1, DXY_ROW_DTYPE).tobytes()
+        ref_tot = rows_from_device(tot1, DXY_TOTAL_DTYPE)[0]
+        # the block-ordered total, formed here by the single-GPU call on a table of 2^16-site blocks
+        starts = np.arange(0, n, TOTAL_BLOCK, dtype=np.uint64)
+        bw = np.zeros(starts.size, dtype=WIN_DTYPE)
+        bw["lo"], bw["hi"], bw["flags"] = starts, np.minimum(starts + np.uint64(TOTAL_BLOCK), np.uint64(n)), 1
+        brow = rows_from_device(ctx.dxy_reduce_dev(*dxy_cols(0, n), minind, windows_to_device(bw, dev))[0], DXY_ROW_DTYPE)
+        acc = 0.0
+        for v in brow["sum"].tolist():
+            acc += v
+    for mode in ("gather", "peer"):
+        rows, total = sharded_dxy_scan(win, n, dxy_cols, ctx, minind, dev, mode=mode, coll_device=cpu)
+        if rank == 0:
+            assert rows.tobytes() == ref_rows, f"dxy rows {mode}"
+            assert int(total["neff"]) == int(ref_tot["neff"]) and int(total["nskip"]) == int(ref_tot["nskip"])
+            assert float(total["sum"]) == acc, (float(total["sum"]), acc)   # bitwise: the block order is the same for any rank count
+            assert abs(float(total["sum"]) - float(ref_tot["sum"])) <= 1e-12 * abs(float(ref_tot["sum"]))
+            print(f"HIP_RANKS_OK dxy {mode}", flush=True)
 
     ctx.close()
     dist.barrier()

@@ -723,7 +723,7 @@ def test_multi_rank_hip_path_two_ranks_one_gpu():
     both on GPU 0, gloo for the collectives: shard plan -> per-rank site range -> real HIP kernels
     through the C-ABI -> rows to rank 0 by the gather AND by peer stores through hipIpc -> bytes equal
     to the single-GPU call.  fst, batched pairs (config 5), AF front end, extreme scan with windows
-    >= 2^20 sites.  See tests/hip_rank_worker.py."""
+    >= 2^20 sites, dxy rows + genome-wide line (sharded_dxy_scan).  See tests/hip_rank_worker.py."""
     import os
     import subprocess
     import sys
@@ -734,7 +734,7 @@ def test_multi_rank_hip_path_two_ranks_one_gpu():
                         "--master-addr", "127.0.0.1", "--master-port", "29541", script],
                        capture_output=True, text=True, env=env, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for tag in ("fst gather", "fst peer", "fst auto", "pairs gather", "pairs peer", "af peer", "extreme peer"):
+    for tag in ("fst gather", "fst peer", "fst auto", "pairs gather", "pairs peer", "af peer", "extreme peer", "dxy gather", "dxy peer"):
         assert "HIP_RANKS_OK " + tag in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
@@ -1033,3 +1033,25 @@ def test_sliding_query_with_batched_pairs_and_fused_statistics(pgt, ctx):
         assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
     finally:
         ctx.set_window_step(0)
+
+
+def test_sharded_dxy_scan_single_process(pgt, ctx):
+    """distributed.sharded_dxy_scan without a process group (one rank): the rows of the plain call, the total's
+    counts exactly and its sum to rounding (the two-rank run of the same function: tests/hip_rank_worker.py)."""
+    import torch
+    from popgenomicstools_amd._lib import DXY_ROW_DTYPE, DXY_TOTAL_DTYPE
+    from popgenomicstools_amd.distributed import sharded_dxy_scan
+    dev = torch.device("cuda:0")
+    n = 700_001  # 10 whole 2^16-site blocks and a ragged one
+    g = _genome(77, n, 3)
+    win = pgt.build_windows_sites(g.run_len, 20_000, 5_000)
+
+    def cols(lo, hi):
+        return (g.pos_t(lo, hi, dev),) + tuple(g.dxy_columns_t(lo, hi, dev))
+    out, tot, _ = ctx.dxy_reduce_dev(*cols(0, n), 5, windows_to_device(win, dev))
+    rows, total = sharded_dxy_scan(win, n, cols, ctx, 5, dev)
+    assert rows.tobytes() == rows_from_device(out, DXY_ROW_DTYPE).tobytes()
+    t = rows_from_device(tot, DXY_TOTAL_DTYPE)[0]
+    assert int(total["neff"]) == int(t["neff"]) and int(total["nskip"]) == int(t["nskip"])
+    assert_close([float(total["sum"])], [float(t["sum"])], "genome-wide dxy")
+    assert int(t["neff"]) + int(t["nskip"]) == n  # every site counted once (minind filter: skipped, not dropped)
