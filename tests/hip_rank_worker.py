@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import popgenomicstools_amd as pgt  # noqa: E402
-from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, EXT_ROW_DTYPE, FST_ROW_DTYPE, PGT_EXT_IHS,  # noqa: E402
+from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, DXY_TOTAL_DTYPE, EXT_ROW_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_EXT_IHS,  # noqa: E402
                                        WIN_DTYPE)
 from popgenomicstools_amd.distributed import TOTAL_BLOCK, sharded_dxy_scan, sharded_scan  # noqa: E402
 from popgenomicstools_amd.window_scan import rows_from_device, windows_to_device  # noqa: E402
@@ -105,6 +105,20 @@ def main():
         assert int((ewin["hi"] - ewin["lo"]).max()) >= 1 << 20
         assert got.tobytes() == ref, "extreme"
         print("HIP_RANKS_OK extreme peer", flush=True)
+
+    # ---- hetWindow (int8 column, 1024-site leaves, 65536-site level-2 nodes = the smallest shard alignment) ----
+    ctx.set_max_window(W)
+
+    def het_cols(lo, hi):
+        return g.pos_t(lo, hi, dev), g.genotype_t(0, lo, hi, dev)
+
+    def het_reduce(c, w, out):
+        ctx.het_reduce_dev(c[0], c[1], windows_to_device(w, dev), out=out)
+    ref = whole(lambda: rows_from_device(ctx.het_reduce_dev(*het_cols(0, n), windows_to_device(win, dev))[0], HET_ROW_DTYPE).tobytes())
+    got = sharded_scan(win, HET_ROW_DTYPE, het_cols, het_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu)
+    if rank == 0:
+        assert got.tobytes() == ref, "het"
+        print("HIP_RANKS_OK het peer", flush=True)
 
     # ---- dxyWindow: window rows + the genome-wide line, bits independent of the rank count ---------
     ctx.set_max_window(W)

@@ -734,7 +734,7 @@ def test_multi_rank_hip_path_two_ranks_one_gpu():
                         "--master-addr", "127.0.0.1", "--master-port", "29541", script],
                        capture_output=True, text=True, env=env, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for tag in ("fst gather", "fst peer", "fst auto", "pairs gather", "pairs peer", "af peer", "extreme peer", "dxy gather", "dxy peer"):
+    for tag in ("fst gather", "fst peer", "fst auto", "pairs gather", "pairs peer", "af peer", "extreme peer", "het peer", "dxy gather", "dxy peer"):
         assert "HIP_RANKS_OK " + tag in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
