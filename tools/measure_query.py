@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Query-kernel time for S << W on one MI355X: fstWindow, 10^8 sites, W = 50000, S in {1, 8, 32, 100, 10000}, with the
-per-window query (step hint 0) and with the sliding query (step hint S; it only switches for S <= 32).  Markdown on stdout."""
+per-window query (step hint 0) and with the sliding query (step hint S; it only switches for S <= 32).  Markdown on stdout.
+usage: measure_query.py [sites [steps,comma,separated [winsize]]]"""
 import os
 import sys
 
@@ -22,7 +23,7 @@ def main():
     g = SynthGenome(12345, n, 20)
     pos, a, b = g.fst_columns_t(0, n, dev)
     ctx = pgt.Context(0)
-    W = 50_000
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
     ctx.set_max_window(W)
     ctx.set_profiling(True)
     tree = torch.empty(ctx.tree_bytes(0, n), dtype=torch.uint8, device=dev)
