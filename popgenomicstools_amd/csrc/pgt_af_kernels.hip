@@ -17,7 +17,7 @@
 // build streams 8 B/site/population (64 B/site for 8 populations) instead of the 16 B/site/pair
 // (448 B/site for 28 pairs) of precomputed component columns.
 //
-// Cross-lane cost: V sums per 128-site leaf tile would be V six-step butterflies; instead a
+// Cross-lane cost: V sums per 256-site leaf node would be V six-step butterflies; instead a
 // REDUCE-SCATTER halves the live values at every exchange step (18+9+5+3+2+1 = 38 exchanges for
 // V = 36), leaving each total in exactly one lane, which stores it and keeps the level-2 running sum.
 #include <hip/hip_runtime.h>
@@ -31,6 +31,18 @@ namespace pgt {
 namespace {
 
 using namespace dev;
+
+// Tree shape of the AF front end: 256-site leaf nodes, 32 of them per level-2 node (8192 sites, as in every other
+// f64 tree), radix 64 above.  Against 128-site leaves (64 per level-2 node, the layout until late in round 2) this
+// halves the node bytes the build writes (3.5 % -> 1.8 % of the bytes read at 8 populations) and the
+// reduce-scatters, and leaves the number and size of the level-2 work items alone: +4.7 / +5.1 / +7.9 points of
+// the HBM peak at 8 / 4 / 2 populations in one session (profiles/r02/af_leaf256.txt).  512-site leaves (16 per
+// level-2 node) gain nothing more on the build within the run-to-run spread and cost the query 25 % (its ragged
+// site ranges double): profiles/r02/af_pieces.txt.  An earlier attempt at 256-site leaves had kept 64 per level-2
+// node: 1-MiB work items, too few of them, no gain.
+constexpr int kAfPieces = 2;                     // 128-site pieces (one 16-byte load per lane and column) per level-1 node
+constexpr int kAfLeaf = kAfPieces * kLeafF64;    // sites per level-1 node
+constexpr int kAfRadix1 = kRadix / kAfPieces;    // level-1 nodes per level-2 node
 
 template <int NP>
 struct Shape {
@@ -124,12 +136,8 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
     return reinterpret_cast<double *>(tv.base + tv.off[level_slot]) + i * V + v;  // node-major: V doubles per node
 }
 
-// ---- BUILD: one wave per level-2 tile (64 leaf tiles of 128 sites) ------------------------------
-// (Tried twice: 256-site leaf tiles, which halve the node bytes and the reduce-scatters.  Round 1, value-major
-// tree: 53.6 % vs 56.7 % of the HBM peak at 8 populations.  Round 2, node-major tree and balanced grid: the
-// node stores then cost 4 points instead of 9, but the larger level-2 tiles (1 MiB of reads, 6104 of them at
-// 10^8 sites) lose as much: 65.8-70.8 % vs 74.9 %.  Kept: 128-site leaves.)
-template <int NP, int ABLATE = 0>  // ABLATE (tuning build only, wrong results): 1 no reduce-scatter, 2 no node stores, 3 no accumulate
+// ---- BUILD: one wave per level-2 tile (64 pieces of 128 sites = 32 leaf nodes of 256) ---------------
+template <int NP, int ABLATE = 0, bool WIDE = true>  // ABLATE (tuning build only, wrong results): 1 no reduce-scatter, 2 no node stores, 3 no accumulate; WIDE = false: 128-site leaves, 64 per tile (timing only)
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
 
@@ -139,18 +147,16 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     const int my = rs_my_index<V>(lane);
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
     // Level-1 nodes are staged in LDS and leave once per level-2 tile as ONE contiguous block (node-major
-    // tree: 64 nodes x V doubles = 18 KiB at 8 populations).  History, 8 populations, % of the HBM peak:
-    // each leaf total stored straight from the lane that held it (36 scattered 8-byte stores per 128-site
-    // tile) 59.6; value-major tree with one 512-byte row per value and tile (36 rows in 36 different
-    // arrays) 57-62; a timing-only build without level-1 stores 76.9.  As in fst_build_kernel what costs
-    // is node writes interleaved with the read stream, here 3.5 % of the bytes.  (Round 2, tried and dropped:
-    // requesting the next level-2 tile's first leaf BEFORE the block is stored, so that no load queues
-    // behind 18 KiB of stores in the in-order vmcnt: 69.6 % vs 71.2 % without, 230 VGPRs instead of 188,
-    // profiles/r02/af_pipe.txt.  Also dropped: TWO level-2 tiles staged per flush (36-KiB bursts, 144 KiB of LDS
-    // per workgroup) and/or three leaves prefetched instead of one (32 loads in flight per lane, 1 wave per
-    // SIMD): 67.9-69.9 % against 69.7 % in the same session, rows identical — profiles/r02/af_stage2.txt.)
+    // tree: 32 nodes x V doubles = 9 KiB at 8 populations).  History with 128-site leaves, 8 populations, % of
+    // the HBM peak: each leaf total stored straight from the lane that held it (36 scattered 8-byte stores per
+    // leaf) 59.6; value-major tree with one 512-byte row per value and tile (36 rows in 36 different arrays)
+    // 57-62; node-major blocks 68-75; a timing-only build without level-1 stores 76.9.  As in fst_build_kernel
+    // what costs is node writes interleaved with the read stream — the cost goes with their BYTES, not with how
+    // they are issued: requesting the next level-2 tile's first leaf BEFORE the block is stored (69.6 vs 71.2 %,
+    // profiles/r02/af_pipe.txt), two level-2 tiles staged per flush and / or three leaves prefetched (67.9-69.9
+    // vs 69.7 %, af_stage2.txt) changed nothing; halving the bytes (256-site leaves) did.
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
-    double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kWave;
+    double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * (WIDE ? kAfRadix1 : kRadix);
 
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
@@ -172,13 +178,15 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             }
         };
         load_tile(cur, 0);
-#pragma unroll 2
-        for (int j = 0; j < kRadix; ++j) {
+        double vals[V];
+#pragma unroll kAfPieces
+        for (int j = 0; j < kRadix; ++j) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
             double2 nxt[NP];
-            if (j + 1 < kRadix) load_tile(nxt, j + 1);  // next tile's loads fly while this one is reduced
-            double vals[V];
+            if (j + 1 < kRadix) load_tile(nxt, j + 1);  // next piece's loads fly while this one is reduced
+            if (!WIDE || (j & (kAfPieces - 1)) == 0) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) vals[v] = 0.0;
+                for (int v = 0; v < V; ++v) vals[v] = 0.0;
+            }
             double fx[NP], fy[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
@@ -189,15 +197,17 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
 #pragma unroll
                 for (int k = 0; k < NP; ++k) vals[k] = fx[k] + fy[k];
             }
-            if constexpr (ABLATE != 1) {
-                rs_steps<V, 0>(vals, lane);
-            } else {  // keeps every value (and every load) alive without any cross-lane step
+            if (!WIDE || (j & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
+                if constexpr (ABLATE != 1) {
+                    rs_steps<V, 0>(vals, lane);
+                } else {  // keeps every value (and every load) alive without any cross-lane step
 #pragma unroll
-                for (int v = 1; v < V; ++v) vals[0] += vals[v];
-            }
-            if (my >= 0) {
-                stage[j * V + my] = vals[0];  // node j of the wave's LDS stage: V consecutive doubles (conflict-free)
-                l2acc += vals[0];
+                    for (int v = 1; v < V; ++v) vals[0] += vals[v];
+                }
+                if (my >= 0) {
+                    stage[(WIDE ? j / kAfPieces : j) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
+                    l2acc += vals[0];
+                }
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
@@ -207,9 +217,10 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
         // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
         // (the stage belongs to this wave alone, LDS operations of a wave complete in order: no barrier)
         {
-            double2 *dst = reinterpret_cast<double2 *>(af_node<V>(tv, 0, 0, t * kRadix));
+            constexpr int kNodes = WIDE ? kAfRadix1 : kRadix;
+            double2 *dst = reinterpret_cast<double2 *>(af_node<V>(tv, 0, 0, t * kNodes));
             const double2 *src = reinterpret_cast<const double2 *>(stage);
-            constexpr int kVec = V * kWave / 2;  // double2 elements of the block
+            constexpr int kVec = V * kNodes / 2;  // double2 elements of the block
 #pragma unroll 4
             for (int e = lane; e < kVec; e += kWave) {
                 const double2 w = src[e];
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32
         uint64_t clo = lo, chi = hi;
         for (int k = 0;; ++k) {
             const bool top = k == tv.n_levels;
-            const uint64_t r = k == 0 ? (uint64_t)kLeafF64 : (uint64_t)kRadix;
+            const uint64_t r = k == 0 ? (uint64_t)kAfLeaf : (k == 1 ? (uint64_t)kAfRadix1 : (uint64_t)kRadix);
             const uint64_t ulo = (clo + r - 1) / r, uhi = chi / r;
             if (top || ulo >= uhi) {
                 if (k == 0) sum_sites(clo, chi); else sum_nodes(k, clo, chi);
@@ -343,13 +354,14 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         const uint64_t rounds = (tl.count[1] + max_waves - 1) / max_waves;
         const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
         uint64_t blocks = (waves + 3) / 4;
-        constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kWave * sizeof(double);  // 4 waves x V rows x 512 B
+        constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x 32 nodes x V doubles
 #ifdef PGT_TUNING_BUILD
         const char *ab = getenv("PGT_AF_ABLATE");
         const int abl = ab ? atoi(ab) : 0;
         if (abl == 1) hipLaunchKernelGGL((af_build_kernel<NP, 1>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         else if (abl == 2) hipLaunchKernelGGL((af_build_kernel<NP, 2>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         else if (abl == 3) hipLaunchKernelGGL((af_build_kernel<NP, 3>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        else if (abl == 20) hipLaunchKernelGGL((af_build_kernel<NP, 0, false>), dim3((unsigned)blocks), dim3(256), 2 * kStage, s, cols, n, tl.count[1], tv);
         else
 #endif
         hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
@@ -378,7 +390,11 @@ namespace {
 template <int NP>
 void af_allow_lds() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)4 * Shape<NP>::kVals * kWave * sizeof(double)));
+                              (int)((size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double)));
+#ifdef PGT_TUNING_BUILD
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)4 * Shape<NP>::kVals * kRadix * sizeof(double)));
+#endif
 }
 }  // namespace
 

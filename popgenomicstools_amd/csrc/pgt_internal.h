@@ -80,9 +80,10 @@ inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
 }
 
 // ---- allele-frequency front end (pgt_af_kernels.hip): nodes of V scalar sums, node-major ------
-// A node is V consecutive doubles (V = NP + NP(NP-1)/2), the nodes of a level are contiguous: the 64
-// level-1 nodes a build wave finishes together are ONE contiguous block of 512*V bytes (18 KiB at 8
-// populations), and a query lane reads a node as one contiguous run.
+// A node is V consecutive doubles (V = NP + NP(NP-1)/2), the nodes of a level are contiguous: the 32
+// level-1 nodes (256 sites each) a build wave finishes together are ONE contiguous block of 256*V bytes (9 KiB
+// at 8 populations), and a query lane reads a node as one contiguous run.  Levels 2 and up are those of the
+// f64 layout (8192 sites, x64 per level).
 constexpr int kAfMaxPops = 8;
 struct AfTree {
     char *base;
@@ -90,7 +91,15 @@ struct AfTree {
     int n_levels;
     int n_vals;              // V: doubles per node
 };
-inline size_t af_level_bytes(const TreeLayout &t, int k, int n_vals) { return ((t.count[k] * (size_t)n_vals * 8 + 255) / 256) * 256; }
+// the AF tree's level 1 holds 32 nodes of 256 sites per level-2 node (pgt_af_kernels.hip), half of the f64 layout's count
+inline size_t af_level_bytes(const TreeLayout &t, int k, int n_vals) {
+#ifdef PGT_TUNING_BUILD
+    const uint64_t nodes = t.count[k];  // room for the 128-site-leaf variant of tools/ablate_af_stores.py
+#else
+    const uint64_t nodes = k == 0 ? t.count[0] / 2 : t.count[k];
+#endif
+    return ((nodes * (size_t)n_vals * 8 + 255) / 256) * 256;
+}
 inline size_t af_tree_bytes(const TreeLayout &t, int n_vals) {
     size_t b = 0;
     for (int k = 0; k < t.n_levels; ++k) b += af_level_bytes(t, k, n_vals);
