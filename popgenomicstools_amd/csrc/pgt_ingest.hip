@@ -428,7 +428,8 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     // memcpy cost more than the overlap buys); hipHostRegister of the mapping + copy: 31 ms/GB to register,
     // then 57.6 GB/s — 156 ms for the same 3.2 GB; four threads each registering, copying and unregistering
     // their own 128-MiB slices: 113-126 ms against 88 ms for the plain copy in the same session (registration
-    // does not scale with threads).  Kept simple.
+    // does not scale with threads); 2 / 4 / 8 threads each copying its slice with hipMemcpyAsync on its own stream,
+    // no explicit pinning: 100 / 137-163 / 179 ms against 83-95 ms for the one plain copy.  Kept simple.
     if (int rc = hip(hipMemcpy(dtxt.p, text, len, hipMemcpyHostToDevice), "upload text")) return rc;
     lap("upload text");
     if (int rc = hip(hipMemsetAsync(static_cast<char *>(dtxt.p) + len, 0, n_blocks * kBlockBytes - len, nullptr), "pad text")) return rc;
