@@ -175,7 +175,7 @@ def extra_configs(ctx, dev, W, S, tree_pool):
                               kernel="fst_build_kernel (grid.y = 28)")
     del al, bl
     # ihsWindow-style extreme-score scan: one f64 score column, 100 kb windows
-    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS, PGT_STAT_EXT
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS
     ewin_h = pgt.build_windows_extreme(pos.cpu().numpy().view(np.uint32), g8.run_len, None, 100_000)
     ewin = windows_to_device(ewin_h, dev)
     erows = torch.empty(ewin_h.size * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)

@@ -1,9 +1,7 @@
 """CPU: the C-ABI library loads without a GPU and exports every symbol include/pgtwin.h declares."""
-import ctypes
 import os
 import re
 
-import numpy as np
 import pytest
 
 from popgenomicstools_amd import _lib

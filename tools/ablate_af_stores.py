@@ -2,7 +2,7 @@
 measured 59.6 % at 8 populations, a timing-only build without them 76.9 %)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
-import bench, popgenomicstools_amd as pgt
+import popgenomicstools_amd as pgt
 from popgenomicstools_amd.window_scan import windows_to_device
 dev = torch.device("cuda", 0); n = 100_000_000
 gen = torch.Generator(device=dev).manual_seed(3)

@@ -58,7 +58,7 @@ def main():
         bm, qm, step = res
         print(f"| {name} | {bps} | {bm:.4f} | {bps * n / bm / 1e6:.0f} | {bps * n / bm / 1e6 / 80:.1f} | {qm:.4f} | {step:.4f} | {n / step * 1e3:.3e} |")
 
-    from popgenomicstools_amd._lib import PGT_STAT_DXY, PGT_STAT_FST, PGT_STAT_HET
+    from popgenomicstools_amd._lib import PGT_STAT_FST
     n_pairs = 2 if big else 28
     tree = torch.empty(n_pairs * ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)  # reused by every config
     out = torch.empty(28 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
@@ -75,13 +75,12 @@ def main():
     row(f"3: dxy + het x2 fused {n:.0e}", 26, timed(ctx, lambda: ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)))
     del p1, p2, n1, n2, g1, g2
     # ihsWindow-style extreme-score scan: one f64 score column, 100 kb non-overlapping windows
-    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_STAT_EXT
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE
     hpos = pos.cpu().numpy().view(np.uint32)
     ewin_h = pgt.build_windows_extreme(hpos, run_len, None, 100_000)
     ewin = windows_to_device(ewin_h, dev)
     eout = torch.empty(ewin_h.size * EXT_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     lib = pgt._lib.load()
-    import ctypes as C
     score = a * 40.0 - 2.0
 
     def ext_call():
