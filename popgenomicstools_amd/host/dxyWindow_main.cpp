@@ -224,10 +224,10 @@ int main(int argc, char **argv) {
         fetch_columns(device.get(), m2);
         size_t r1 = 0, r2 = 0, o1 = 0, o2 = 0;
         while (r1 < m1.runs.name.size() && r2 < m2.runs.name.size()) {
-            const std::string &c1 = m1.runs.name[r1], &c2 = m2.runs.name[r2];
-            if (c1 != c2) {  // skip the run that the other file does not have next
+            const std::string &chr1 = m1.runs.name[r1], &chr2 = m2.runs.name[r2];
+            if (chr1 != chr2) {  // skip the run that the other file does not have next
                 bool later_in_1 = false;
-                for (size_t k = r1 + 1; k < m1.runs.name.size() && !later_in_1; ++k) later_in_1 = m1.runs.name[k] == c2;
+                for (size_t k = r1 + 1; k < m1.runs.name.size() && !later_in_1; ++k) later_in_1 = m1.runs.name[k] == chr2;
                 if (later_in_1) { o1 += m1.runs.len[r1]; ++r1; } else { o2 += m2.runs.len[r2]; ++r2; }
                 continue;
             }
@@ -244,7 +244,7 @@ int main(int argc, char **argv) {
                     ++i; ++j;
                 }
             }
-            if (pos_v.size() > before) runs.add(c1.data(), c1.data() + c1.size(), pos_v.size() - before);
+            if (pos_v.size() > before) runs.add(chr1.data(), chr1.data() + chr1.size(), pos_v.size() - before);
             o1 = e1; o2 = e2; ++r1; ++r2;
         }
         pos = pos_v.data(); p1 = p1_v.data(); p2 = p2_v.data(); n1 = n1_v.data(); n2 = n2_v.data();
