@@ -786,6 +786,7 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
 // windows take the plain range query of query_body — one by one, after the group's common work.
 // ------------------------------------------------------------------------------------------
 constexpr int kSlideTile = 128;
+constexpr int kSlideDirect = 32;  // windows of at most this many sites are summed by their lane alone, site by site
 template <class Node>
 __device__ __forceinline__ Node node_from_lane(const Node &v, int src_lane) {
     constexpr int kWords = sizeof(Node) / 4;
@@ -869,6 +870,21 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
         const uint64_t lo = wd.lo < hi ? wd.lo : hi;
         const uint64_t tl = lo / kSlideTile, th = hi / kSlideTile;
         const uint32_t offl = (uint32_t)(lo % kSlideTile), offh = (uint32_t)(hi % kSlideTile);
+        // Windows of a few sites (`-winsize 1 -stepsize 1`, the per-site mode dxyWindow.cpp:47 documents): the lane
+        // adds its own window's sites from left to right — the reference's own order (fstWindow.cpp:76-83) — instead
+        // of taking part in up to 64 wave-wide queries, one per window that does not reach a tile boundary.
+        const bool tiny = active && hi > lo && hi - lo <= (uint64_t)kSlideDirect;
+        if (tiny) {
+            Node acc = none;
+            for (uint64_t i = lo; i < hi; ++i) node_add(acc, Tr::leaf(c, i));
+            uint32_t start = wd.start, end = wd.end;
+            if (!(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
+                start = pos[lo];
+                end = pos[hi - 1];
+            }
+            Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
+        }
+        if (__ballot(active && !tiny) == 0) continue;  // wave-uniform: nothing left that needs the scans
         // the group's first start tile / end tile (wave-uniform)
         uint64_t tl0 = active ? tl : ~0ull, th0 = active ? th : ~0ull;
 #pragma unroll
@@ -885,7 +901,7 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
                 scan_tile(side, (side ? th0 : tl0) + (uint64_t)k, span + (side * 2 + k) * kSlideTile);
         // the wave's own LDS rows: LDS operations of one wave complete in order, no barrier needed
         const uint64_t A = offl ? (tl + 1) * kSlideTile : lo, B = th * kSlideTile;
-        const bool fast = active && hi > lo && tl - tl0 <= 1 && th - th0 <= 1 && A <= B;
+        const bool fast = active && !tiny && hi > lo && tl - tl0 <= 1 && th - th0 <= 1 && A <= B;
         Node left = none, right = none;
         if (fast && offl) left = span[(0 * 2 + (int)(tl - tl0)) * kSlideTile + offl];
         if (fast && offh) right = span[(1 * 2 + (int)(th - th0)) * kSlideTile + offh - 1];
@@ -911,7 +927,7 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
         // windows outside the group's tiles: the same three pieces from scans of their own tiles; windows
         // shorter than the split allows (A > B) or empty: the plain range query.  Either way the order
         // of the sums depends on the window alone.
-        bool slow = active && !fast;
+        bool slow = active && !fast && !tiny;
         for (unsigned long long m = __ballot(slow); m != 0; m = __ballot(slow)) {
             const int L = __ffsll((long long)m) - 1;
             const uint64_t lo_u = __shfl(lo, L, kWave), hi_u = __shfl(hi, L, kWave);
