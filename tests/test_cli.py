@@ -182,6 +182,44 @@ def test_dxy_cli_intersects_site_sets(hosts, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_dxy_cli_random_modes_vs_oracle_text(hosts, tmp_path, oracle):
+    """dxyWindow end to end (MAF text -> parse -> site or bp windows -> GPU -> TSV + the genome-wide line) against the
+    oracle's text front end, on random layouts and option mixes: fixed-site and bp windows, window = step and
+    window > step, per-site (1/1), global (-winsize 0), -skip_missing, minind above and below the counts."""
+    rng = np.random.default_rng(77)
+    hdr = helpers.load_golden("dxy_kat.json")["header"]
+    m1, m2, sz, o, e = (tmp_path / n for n in ("a.mafs", "b.mafs", "sizes.txt", "o.txt", "e.txt"))
+    checked = 0
+    for trial in range(24):
+        rows1, rows2, sizes = [], [], []
+        for c in range(int(rng.integers(1, 5))):
+            L = int(rng.integers(5, 400))
+            k = int(rng.integers(1, min(L, 120) + 1))
+            ps = np.sort(rng.choice(np.arange(1, L + 1), size=k, replace=False))
+            sizes.append((f"chr{c + 1}", L + int(rng.integers(0, 30))))
+            for p_ in ps:
+                rows1.append((f"chr{c + 1}", int(p_), round(float(rng.uniform(0, 1)), 6), int(rng.integers(0, 12))))
+                rows2.append((f"chr{c + 1}", int(p_), round(float(rng.uniform(0, 1)), 6), int(rng.integers(0, 12))))
+        _write_maf(m1, hdr, rows1); _write_maf(m2, hdr, rows2)
+        sz.write_text("".join(f"{c}\t{n}\n" for c, n in sizes))
+        fixed = int(rng.integers(0, 2))
+        W = int(rng.choice([0, 1, 2, 7, 25, 60])) if fixed else int(rng.choice([1, 3, 10, 40, 100]))
+        S = 0 if W == 0 else int(rng.integers(1, W + 1))
+        minind, skip = int(rng.integers(1, 9)), int(rng.integers(0, 2))
+        assert oracle.dxy_text(str(m1), str(m2), None if fixed else str(sz), W, S, minind, fixed, skip, str(o), str(e)) == 0
+        cmd = [hosts["dxyWindow"], "-winsize", str(W), "-stepsize", str(S), "-minind", str(minind), "-fixedsite", str(fixed),
+               "-skip_missing", str(skip)]
+        if not fixed:
+            cmd += ["-sizefile", str(sz)]
+        r = run(cmd + [str(m1), str(m2)])
+        assert r.returncode == 0, (cmd, r.stderr)
+        tsv_equal(r.stdout, o.read_text(), 3)
+        tsv_equal(r.stderr, e.read_text(), 0)
+        checked += len(r.stdout.splitlines())
+    assert checked > 300
+
+
+@pytest.mark.gpu
 def test_cli_step_one_regime(hosts, tmp_path, oracle):
     """S=1 (one window per site): O(N·W) for the reference, O(N·64·log W) here; the
     block-parallel TSV writer must keep row order.  Checked against the oracle's text front end."""
