@@ -437,3 +437,51 @@ def test_gpu_ingest_cli_equals_host_parser(hosts, tmp_path):
     _write_maf(m2, k["header"], [k["pop2"][0], ["cA", 3, 1.5, 4]])  # frequency outside [0,1]
     r = both([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-fixedsite", "1", str(m1), str(m2)])
     assert r.returncode == 255 and "line 3" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
+    """Where oracle/_ref holds the compiled, unmodified reference tools (this container, and the GPU box, which
+    receives them with the snapshot): fresh random inputs — other seeds than the committed goldens — through the
+    reference binary and through the host, stdout compared (fstWindow: the %g column to its last printed digit;
+    hetWindow, ihsWindow, xpehhWindow: byte for byte)."""
+    import importlib.util
+    import random
+    import oracle_bind
+    if not all(oracle_bind.ref_binary(t) for t in ("fstWindow", "hetWindow", "ihsWindow", "xpehhWindow")):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rng = random.Random(20261004)
+    exact = total = 0
+    for tool in ("fstWindow", "hetWindow"):
+        for _ in range(25):
+            text, W, S = mg.random_case(rng, tool, max_chr=6, max_sites=60, max_w=25)
+            f = tmp_path / "in.txt"
+            f.write_text(text)
+            ref = run([oracle_bind.ref_binary(tool), str(f), str(W), str(S)])
+            mine = run([hosts[tool], str(f), str(W), str(S)])
+            assert mine.returncode == 0 and ref.returncode == 0, (tool, W, S, mine.stderr)
+            if tool == "fstWindow":
+                tsv_equal(mine.stdout, ref.stdout, 4)
+            else:
+                assert mine.stdout == ref.stdout, (tool, W, S)
+            exact += mine.stdout == ref.stdout
+            total += 1
+    for tool in ("ihsWindow", "xpehhWindow"):
+        for _ in range(20):
+            files, args = mg.extreme_case(rng, tool, max_chr=5, max_sites=60)
+            paths = {}
+            for name, text in files.items():
+                p = tmp_path / name
+                p.write_text(text)
+                paths[name] = str(p)
+            argv = [paths[a[1:]] if a.startswith("@") else a for a in args]
+            ref = run([oracle_bind.ref_binary(tool)] + argv)
+            mine = run([hosts_ext[tool]] + argv)
+            assert mine.returncode == 0 and ref.returncode == 0, (tool, args, mine.stderr)
+            assert mine.stdout == ref.stdout, (tool, args)
+            exact += 1
+            total += 1
+    assert exact >= total - 3  # fstWindow rows may differ in the sixth digit of a ratio; in practice none does
