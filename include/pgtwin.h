@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PGT_ABI_VERSION 2
+#define PGT_ABI_VERSION 3
 
 enum {
     PGT_OK = 0,
@@ -302,6 +302,30 @@ int64_t pgt_ingest_bad_line(const pgt_ingest *ing);
 void *pgt_ingest_column(const pgt_ingest *ing, int token);
 size_t pgt_ingest_runs(const pgt_ingest *ing, const uint64_t **run_len, const uint64_t **name_off, const uint32_t **name_len);
 void pgt_ingest_free(pgt_ingest *ing);
+
+/* ---- window tables built ON the device (the `-stepsize 1` regime) -------------------
+ * With one window per site the table of pgt_build_windows_sites is as large as the columns (32 B per window)
+ * and the host spends its time filling and uploading it.  pgt_wintab_sites builds the SAME table — same rules
+ * (fstWindow.cpp:132-138,150-152 with calcWindow's carry :92-103), same bytes — in GPU memory from the
+ * chromosome run lengths: the host plans every run in O(#runs), a kernel writes the windows.
+ * pgt_wintab_first: n_runs + 1 values, the index of every run's first window (the last = the number of windows):
+ * row i carries the name of the run r with first[r] <= i < first[r+1] (pgt_win.label_run of the host table).
+ * pgt_wintab_device: the table itself, a DEVICE pointer usable as `win` of the *_dev calls.
+ * *_reduce_tab: the host-buffer entry points (cols_on_device = 0: pos / a / b ... are host arrays, uploaded here)
+ * or the *_reduce_cols ones (cols_on_device = 1) over such a table; rows come back to HOST memory; synchronous. */
+typedef struct pgt_wintab pgt_wintab;
+int pgt_wintab_sites(pgt_ctx *ctx, const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S, pgt_wintab **out);
+uint64_t pgt_wintab_size(const pgt_wintab *tab);
+const uint64_t *pgt_wintab_first(const pgt_wintab *tab);
+const pgt_win *pgt_wintab_device(const pgt_wintab *tab);
+void pgt_wintab_free(pgt_wintab *tab);
+int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n, int cols_on_device,
+                       const pgt_wintab *tab, pgt_fst_row *out);
+int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, int cols_on_device,
+                       const pgt_wintab *tab, pgt_het_row *out);
+int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
+                       const int32_t *n2, uint64_t n, int minind, int cols_on_device, const pgt_wintab *tab,
+                       pgt_dxy_row *out, pgt_dxy_total *tot);
 
 #ifdef __cplusplus
 }

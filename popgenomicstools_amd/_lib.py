@@ -46,6 +46,8 @@ SYMBOLS = [
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
     "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
     "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
+    "pgt_wintab_sites", "pgt_wintab_size", "pgt_wintab_first", "pgt_wintab_device", "pgt_wintab_free",
+    "pgt_fst_reduce_tab", "pgt_het_reduce_tab", "pgt_dxy_reduce_tab",
 ]
 PGT_TOK_CHR, PGT_TOK_SKIP, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_FREQ = range(7)
 
@@ -127,6 +129,18 @@ def load() -> C.CDLL:
     lib.pgt_ingest_runs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.pgt_ingest_free.restype = None
     lib.pgt_ingest_free.argtypes = [vp]
+    lib.pgt_wintab_sites.argtypes = [vp, vp, sz, u32, u32, C.POINTER(vp)]
+    lib.pgt_wintab_size.restype = u64
+    lib.pgt_wintab_size.argtypes = [vp]
+    lib.pgt_wintab_first.restype = vp
+    lib.pgt_wintab_first.argtypes = [vp]
+    lib.pgt_wintab_device.restype = vp
+    lib.pgt_wintab_device.argtypes = [vp]
+    lib.pgt_wintab_free.restype = None
+    lib.pgt_wintab_free.argtypes = [vp]
+    lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp]
+    lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp]
+    lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, vp]
     for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
         getattr(lib, name)
     _lib = lib

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -531,6 +532,151 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
     if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
     return pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p), static_cast<double *>(d2.p),
                                static_cast<int32_t *>(dn1.p), static_cast<int32_t *>(dn2.p), n, minind, win, n_win, out, tot);
+}
+
+/* ---------------- window tables built on the device ---------------- */
+
+struct pgt_wintab {
+    int device = 0;
+    uint64_t n_win = 0;
+    uint32_t W = 0, S = 0;
+    std::vector<uint64_t> first;  // n_runs + 1
+    pgt_win *d_win = nullptr;
+};
+
+int pgt_wintab_sites(pgt_ctx *ctx, const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S, pgt_wintab **out) {
+    PGT_USE_DEVICE(ctx);
+    if (!out) return ctx_fail(ctx, PGT_EARG, "pgt_wintab_sites: NULL argument");
+    std::vector<RunPlan> plan;
+    uint64_t count = 0;
+    if (int rc = plan_site_windows(run_len, n_runs, W, S, plan, &count)) return ctx_fail(ctx, rc, global_error());
+    std::unique_ptr<pgt_wintab> tab(new pgt_wintab);
+    tab->device = ctx->device;
+    tab->n_win = count;
+    tab->W = W;
+    tab->S = S;
+    tab->first.resize(n_runs + 1);
+    for (size_t r = 0; r < n_runs; ++r) tab->first[r] = plan[r].out0;
+    tab->first[n_runs] = count;
+    if (count) {
+        DevBuf dplan;
+        if (int rc = dplan.upload(ctx, plan.data(), plan.size() * sizeof(RunPlan), "upload window plan")) return rc;
+        void *p = nullptr;
+        if (int rc = hip_check(ctx, hipMalloc(&p, count * sizeof(pgt_win)), "alloc window table")) return rc;
+        tab->d_win = static_cast<pgt_win *>(p);
+        int rc = launch_windows_from_plan(static_cast<const RunPlan *>(dplan.p), n_runs, count, W, S, tab->d_win, nullptr, &ctx->error);
+        if (!rc) rc = hip_check(ctx, hipStreamSynchronize(nullptr), "window table kernel");  // dplan is freed on return
+        if (rc) {
+            (void)hipFree(tab->d_win);
+            return rc;
+        }
+    }
+    *out = tab.release();
+    return PGT_OK;
+}
+
+uint64_t pgt_wintab_size(const pgt_wintab *tab) { return tab ? tab->n_win : 0; }
+const uint64_t *pgt_wintab_first(const pgt_wintab *tab) { return tab ? tab->first.data() : nullptr; }
+const pgt_win *pgt_wintab_device(const pgt_wintab *tab) { return tab ? tab->d_win : nullptr; }
+void pgt_wintab_free(pgt_wintab *tab) {
+    if (!tab) return;
+    int saved = -1;
+    const bool sw = hipGetDevice(&saved) == hipSuccess && saved != tab->device && hipSetDevice(tab->device) == hipSuccess;
+    if (tab->d_win) (void)hipFree(tab->d_win);
+    if (sw) (void)hipSetDevice(saved);
+    delete tab;
+}
+
+namespace {
+// the hints a table built from (W, S) implies, for the duration of one reduce
+struct TabHints {
+    pgt_ctx *ctx;
+    pgt::Hints saved;
+    TabHints(pgt_ctx *c, const pgt_wintab *t) : ctx(c), saved(c->hints) {
+        c->hints.max_window = t->W;
+        c->hints.window_step = t->S;
+    }
+    ~TabHints() { ctx->hints = saved; }
+};
+int tab_check(pgt_ctx *ctx, const pgt_wintab *tab, const void *out, const char *who) {
+    if (!tab || (tab->n_win && !out)) return ctx_fail(ctx, PGT_EARG, std::string(who) + ": NULL argument");
+    if (tab->device != ctx->device) return ctx_fail(ctx, PGT_EARG, std::string(who) + ": the window table lives on another device");
+    return PGT_OK;
+}
+}  // namespace
+
+int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n, int cols_on_device,
+                       const pgt_wintab *tab, pgt_fst_row *out) {
+    PGT_USE_DEVICE(ctx);
+    if (int rc = tab_check(ctx, tab, out, "pgt_fst_reduce_tab")) return rc;
+    if (n && (!pos || !a || !b)) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce_tab: NULL argument");
+    if (tab->n_win == 0) return PGT_OK;
+    DevBuf dpos, da, db, dout, dtree;
+    if (!cols_on_device) {
+        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+        if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
+        if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+        pos = static_cast<uint32_t *>(dpos.p); a = static_cast<double *>(da.p); b = static_cast<double *>(db.p);
+    }
+    const TabHints hint(ctx, tab);
+    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_fst_reduce_dev(ctx, pos, a, b, n, tab->d_win, tab->n_win, static_cast<pgt_fst_row *>(dout.p), dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
+    return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
+}
+
+int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, int cols_on_device, const pgt_wintab *tab,
+                       pgt_het_row *out) {
+    PGT_USE_DEVICE(ctx);
+    if (int rc = tab_check(ctx, tab, out, "pgt_het_reduce_tab")) return rc;
+    if (n && (!pos || !g)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce_tab: NULL argument");
+    if (tab->n_win == 0) return PGT_OK;
+    DevBuf dpos, dg, dout, dtree;
+    if (!cols_on_device) {
+        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+        if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+        pos = static_cast<uint32_t *>(dpos.p); g = static_cast<int8_t *>(dg.p);
+    }
+    const TabHints hint(ctx, tab);
+    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_het_reduce_dev(ctx, pos, g, n, tab->d_win, tab->n_win, static_cast<pgt_het_row *>(dout.p), dtree.p, tb, nullptr)) return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
+    return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
+}
+
+int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
+                       uint64_t n, int minind, int cols_on_device, const pgt_wintab *tab, pgt_dxy_row *out, pgt_dxy_total *tot) {
+    PGT_USE_DEVICE(ctx);
+    if (int rc = tab_check(ctx, tab, out, "pgt_dxy_reduce_tab")) return rc;
+    if (n && (!pos || !p1 || !p2 || !n1 || !n2)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce_tab: NULL argument");
+    DevBuf dpos, d1, d2, dn1, dn2, dout, dtot, dtree;
+    if (!cols_on_device) {
+        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+        if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;
+        if (int rc = d2.upload(ctx, p2, n * sizeof(double), "upload p2")) return rc;
+        if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
+        if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
+        pos = static_cast<uint32_t *>(dpos.p); p1 = static_cast<double *>(d1.p); p2 = static_cast<double *>(d2.p);
+        n1 = static_cast<int32_t *>(dn1.p); n2 = static_cast<int32_t *>(dn2.p);
+    }
+    const TabHints hint(ctx, tab);
+    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
+    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
+    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
+    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
+    if (int rc = pgt_dxy_reduce_dev(ctx, pos, p1, p2, n1, n2, n, minind, tab->d_win, tab->n_win, static_cast<pgt_dxy_row *>(dout.p),
+                                    tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb, nullptr))
+        return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
+    if (tab->n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
+    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
+    return PGT_OK;
 }
 
 /* copy of a device column of an ingest object to the host (dxyWindow's site synchronisation and bp-window

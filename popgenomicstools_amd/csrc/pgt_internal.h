@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "pgtwin.h"
 
@@ -154,6 +155,20 @@ int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, d
 int launch_fst_af(const uint32_t *pos, const double *const *freq, const double *nsamp, uint32_t n_pops,
                   uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
                   void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints);
+
+// pgt_windows.cpp: the site-window rules per chromosome run in closed form (see there); plain data, also read by
+// the kernel that writes a window table on the device (pgt_kernels.hip: launch_windows_from_plan)
+struct RunPlan {
+    uint64_t out0 = 0;  // index of the run's first window in the table
+    uint64_t K = 0;     // full windows [hi0 + k*S - W, hi0 + k*S), k < K
+    uint64_t hi0 = 0;
+    uint64_t tail_lo = 0, tail_hi = 0;  // one more window [tail_lo, tail_hi) at the end of the run ...
+    uint32_t tail = 0, pad_ = 0;        // ... if tail != 0
+};
+// -> PGT_OK and the plan of (run_len, W, S) in site mode + the number of windows; argument errors as pgt_build_windows_sites
+int plan_site_windows(const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S, std::vector<RunPlan> &plan, uint64_t *count);
+int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_win, uint32_t W, uint32_t S, pgt_win *d_out,
+                             void *stream, std::string *err);
 
 // pgt_ingest.hip: text -> device columns + chromosome runs (synchronous, default stream of `device`)
 int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err);

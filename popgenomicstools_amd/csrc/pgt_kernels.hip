@@ -1062,7 +1062,50 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
 #include "pgt_build_experiments.inc"
 #endif
 
+// ------------------------------------------------------------------------------------------
+// The site-window table written on the device from the per-run plan (pgt_windows.cpp: plan_entry_windows /
+// for_each_window are the host form of exactly this): thread i finds its run by bisection over the runs'
+// first window indices and writes window i.  40 B of plan per run in, 32 B per window out.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void windows_from_plan_kernel(const RunPlan *__restrict__ plan, uint64_t n_runs, uint64_t n_win,
+                                                                uint32_t W, uint32_t S, pgt_win *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_win; i += stride) {
+        uint64_t lo = 0, hi = n_runs;  // the last run with out0 <= i: a run that emits nothing shares its out0 with its
+        while (hi - lo > 1) {          // successor, so the last one is the run that holds window i
+            const uint64_t mid = (lo + hi) / 2;
+            if (plan[mid].out0 <= i) lo = mid; else hi = mid;
+        }
+        uint64_t r = lo;
+        while (r > 0 && i - plan[r].out0 >= plan[r].K + plan[r].tail) --r;  // (cannot happen for a consistent plan)
+        const RunPlan p = plan[r];
+        const uint64_t k = i - p.out0;
+        pgt_win w;
+        if (k < p.K) {
+            w.hi = p.hi0 + k * S;
+            w.lo = w.hi - W;
+        } else {
+            w.lo = p.tail_lo;
+            w.hi = p.tail_hi;
+        }
+        w.label_run = (uint32_t)r;
+        w.flags = 0;
+        w.start = w.end = 0;
+        out[i] = w;
+    }
+}
+
 }  // namespace
+
+int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_win, uint32_t W, uint32_t S, pgt_win *d_out,
+                             void *stream, std::string *err) {
+    if (n_win == 0) return PGT_OK;
+    uint64_t blocks = (n_win + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(windows_from_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_plan, n_runs,
+                       n_win, W, S, d_out);
+    return hip_fail(hipGetLastError(), "windows_from_plan_kernel", err);
+}
 
 // Called once from pgt_open: declares the dynamic-LDS needs of the staged build kernels, so that no
 // attribute call can fall inside a caller's stream capture.

@@ -36,14 +36,6 @@ thread_local std::string g_error;
 //                        windows (an arithmetic progression: hi_k = hi0 + k*S) and its end-of-run window;
 //   for_each_window      every window by index, in parallel chunks once there are many (the
 //                        `-stepsize 1` regime: as many windows as sites).
-struct RunPlan {
-    uint64_t out0 = 0;  // index of the run's first window in the table
-    uint64_t K = 0;     // full windows [hi0 + k*S - W, hi0 + k*S), k < K
-    uint64_t hi0 = 0;
-    bool tail = false;  // one more window [tail_lo, tail_hi) at the end of the run
-    uint64_t tail_lo = 0, tail_hi = 0;
-};
-
 uint64_t plan_entry_windows(const uint64_t *entries, size_t n_runs, uint32_t W, uint32_t S, bool bp_rules,
                             std::vector<RunPlan> &plan) {
     plan.assign(n_runs, RunPlan{});
@@ -61,7 +53,7 @@ uint64_t plan_entry_windows(const uint64_t *entries, size_t n_runs, uint32_t W, 
         const uint64_t n_end = n0 + L - p.K * S;
         g += L;
         const bool last = r + 1 == n_runs;
-        auto tail = [&] { p.tail = true; p.tail_lo = g - n_end; p.tail_hi = g; };
+        auto tail = [&] { p.tail = 1; p.tail_lo = g - n_end; p.tail_hi = g; };
         if (last) {  // fstWindow.cpp:150-152 / dxyWindow.cpp:424-426
             if (n_end > (uint64_t)(W - S) && n_end <= W) tail();
             n0 = 0;
@@ -120,6 +112,16 @@ int fail(int code, const std::string &msg) {
 
 }  // namespace
 
+int plan_site_windows(const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S, std::vector<RunPlan> &plan, uint64_t *count) {
+    if (!count || (n_runs && !run_len)) return fail(PGT_EARG, "site windows: NULL argument");
+    // the reference segfaults or exits outside 1 <= S <= W (SURVEY.md §4 Q9); refuse instead
+    if (W < 1 || S < 1 || S > W) return fail(PGT_EARG, "window size and step must satisfy 1 <= step <= window");
+    for (size_t r = 0; r < n_runs; ++r)
+        if (run_len[r] == 0) return fail(PGT_EARG, "site windows: empty chromosome run");
+    *count = plan_entry_windows(run_len, n_runs, W, S, false, plan);
+    return PGT_OK;
+}
+
 void set_global_error(const std::string &msg) { g_error = msg; }
 const std::string &global_error() { return g_error; }
 
@@ -129,13 +131,10 @@ using namespace pgt;
 
 extern "C" int pgt_build_windows_sites(const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S,
                                        pgt_win *out, size_t cap, size_t *n_out) {
-    if (!n_out || (n_runs && !run_len)) return fail(PGT_EARG, "pgt_build_windows_sites: NULL argument");
-    // the reference segfaults or exits outside 1 <= S <= W (SURVEY.md §4 Q9); refuse instead
-    if (W < 1 || S < 1 || S > W) return fail(PGT_EARG, "window size and step must satisfy 1 <= step <= window");
-    for (size_t r = 0; r < n_runs; ++r)
-        if (run_len[r] == 0) return fail(PGT_EARG, "pgt_build_windows_sites: empty chromosome run");
+    if (!n_out) return fail(PGT_EARG, "pgt_build_windows_sites: NULL argument");
     std::vector<RunPlan> plan;
-    const uint64_t count = plan_entry_windows(run_len, n_runs, W, S, false, plan);
+    uint64_t count = 0;
+    if (int rc = plan_site_windows(run_len, n_runs, W, S, plan, &count)) return rc;
     *n_out = (size_t)count;
     if (out)
         for_each_window(plan, std::min<uint64_t>(count, cap), W, S, [&](uint64_t i, uint64_t lo, uint64_t hi, uint32_t label) {

@@ -166,6 +166,39 @@ class Ingest:
             pass
 
 
+class WindowTable:
+    """A site-window table built on the GPU (pgt_wintab_sites): `n_win` windows, `first[r]` = index of run r's
+    first window (n_runs + 1 values), `device()` = the table as a uint8 view usable as `win` of the *_dev calls."""
+
+    def __init__(self, ctx, handle, n_runs):
+        self._ctx, self._h = ctx, handle
+        lib = ctx._lib
+        self.n_win = int(lib.pgt_wintab_size(handle))
+        self.first = np.ctypeslib.as_array(C.cast(lib.pgt_wintab_first(handle), C.POINTER(C.c_uint64)), shape=(n_runs + 1,)).copy()
+
+    def device(self):
+        return RowBuffer(self._ctx._lib.pgt_wintab_device(self._h) or 0, self.n_win * WIN_DTYPE.itemsize, owner=self)
+
+    def to_host(self) -> np.ndarray:
+        raw = self._ctx.rowbuf_read(self.device()) if self.n_win else np.zeros(0, np.uint8)
+        return raw.view(WIN_DTYPE)
+
+    def labels(self) -> np.ndarray:
+        """label_run of every window, from `first` alone"""
+        return (np.searchsorted(self.first, np.arange(self.n_win, dtype=np.uint64), side="right") - 1).astype(np.uint32)
+
+    def free(self):
+        if self._h:
+            self._ctx._lib.pgt_wintab_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------------------
 # context
 # ---------------------------------------------------------------------------------------------
@@ -300,6 +333,48 @@ class Context:
         text = bytes(text)
         self._check(self._lib.pgt_ingest_text(self._ctx, text if text else None, len(text), toks, len(tokens), C.byref(h)))
         return Ingest(self, h, text, tokens)
+
+    # ---- window tables built on the device (pgt_wintab_*) -----------------------------------
+    def window_table_sites(self, run_len, W: int, S: int) -> WindowTable:
+        run_len = np.ascontiguousarray(run_len, dtype=np.uint64)
+        h = C.c_void_p(0)
+        self._check(self._lib.pgt_wintab_sites(self._ctx, run_len.ctypes.data, run_len.size, int(W), int(S), C.byref(h)))
+        return WindowTable(self, h, run_len.size)
+
+    def fst_reduce_tab(self, pos, a, b, tab: WindowTable) -> np.ndarray:
+        """Host columns + a device window table -> host rows (pgt_fst_reduce_tab)."""
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if not (pos.size == a.size == b.size):
+            raise PgtError(_lib.PGT_EARG, "fst_reduce_tab: column lengths differ")
+        out = np.zeros(tab.n_win, dtype=FST_ROW_DTYPE)
+        self._check(self._lib.pgt_fst_reduce_tab(self._ctx, pos.ctypes.data, a.ctypes.data, b.ctypes.data, pos.size, 0, tab._h,
+                                                 out.ctypes.data))
+        return out
+
+    def het_reduce_tab(self, pos, g, tab: WindowTable) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        g = np.ascontiguousarray(g, dtype=np.int8)
+        if pos.size != g.size:
+            raise PgtError(_lib.PGT_EARG, "het_reduce_tab: column lengths differ")
+        out = np.zeros(tab.n_win, dtype=HET_ROW_DTYPE)
+        self._check(self._lib.pgt_het_reduce_tab(self._ctx, pos.ctypes.data, g.ctypes.data, pos.size, 0, tab._h, out.ctypes.data))
+        return out
+
+    def dxy_reduce_tab(self, pos, p1, p2, n1, n2, minind, tab: WindowTable):
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        p1 = np.ascontiguousarray(p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(p2, dtype=np.float64)
+        n1 = np.ascontiguousarray(n1, dtype=np.int32)
+        n2 = np.ascontiguousarray(n2, dtype=np.int32)
+        if not (pos.size == p1.size == p2.size == n1.size == n2.size):
+            raise PgtError(_lib.PGT_EARG, "dxy_reduce_tab: column lengths differ")
+        out = np.zeros(tab.n_win, dtype=DXY_ROW_DTYPE)
+        tot = np.zeros(1, dtype=DXY_TOTAL_DTYPE)
+        self._check(self._lib.pgt_dxy_reduce_tab(self._ctx, pos.ctypes.data, p1.ctypes.data, p2.ctypes.data, n1.ctypes.data,
+                                                 n2.ctypes.data, pos.size, int(minind), 0, tab._h, out.ctypes.data, tot.ctypes.data))
+        return out, tot[0]
 
     # ---- multi-GPU row buffer (pgt_rowbuf_*) ------------------------------------------------
     def rowbuf_create(self, nbytes: int):

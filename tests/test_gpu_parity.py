@@ -1055,3 +1055,48 @@ def test_sharded_dxy_scan_single_process(pgt, ctx):
     assert int(total["neff"]) == int(t["neff"]) and int(total["nskip"]) == int(t["nskip"])
     assert_close([float(total["sum"])], [float(t["sum"])], "genome-wide dxy")
     assert int(t["neff"]) + int(t["nskip"]) == n  # every site counted once (minind filter: skipped, not dropped)
+
+
+def test_device_built_window_table_is_the_host_table(pgt, ctx):
+    """pgt_wintab_sites: the table written by the kernel from the per-run plan is, byte for byte, the table of
+    pgt_build_windows_sites — random chromosome runs, windows and steps (carry and tail rules, runs shorter than a
+    window, step 1), and the run offsets give every row its label."""
+    rng = np.random.default_rng(314)
+    cases = [([1], 1, 1), ([5], 10, 3), ([10, 1, 1, 30], 4, 4), ([7, 7, 7], 7, 1), ([1000003], 50000, 1), ([300000] * 7, 1000, 999)]
+    for _ in range(150):
+        n_runs = int(rng.integers(1, 12))
+        W = int(rng.integers(1, 60))
+        cases.append(([int(x) for x in rng.integers(1, 200, n_runs)], W, int(rng.integers(1, W + 1))))
+    total = 0
+    for run_len, W, S in cases:
+        run_len = np.array(run_len, dtype=np.uint64)
+        host = pgt.build_windows_sites(run_len, W, S)
+        tab = ctx.window_table_sites(run_len, W, S)
+        assert tab.n_win == host.size, (run_len, W, S)
+        assert tab.to_host().tobytes() == host.tobytes(), (run_len, W, S)
+        assert np.array_equal(tab.labels(), host["label_run"])
+        assert tab.first[0] == 0 and tab.first[-1] == host.size and np.all(np.diff(tab.first.astype(np.int64)) >= 0)
+        total += host.size
+        tab.free()
+    assert total > 900_000
+
+
+def test_reduce_over_a_device_table_equals_reduce_over_the_host_table(pgt, ctx):
+    """*_reduce_tab (columns from the host, window table built on the device) against the host-buffer entry points:
+    the same bytes, for a per-site table (W = S = 1), a sliding one and an ordinary one."""
+    rng = np.random.default_rng(315)
+    n = 400_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    run_len = pgt.run_lengths(chr_ids)
+    for W, S in ((1, 1), (300, 1), (5_000, 1_000)):
+        win = pgt.build_windows_sites(run_len, W, S)
+        tab = ctx.window_table_sites(run_len, W, S)
+        assert ctx.fst_reduce_tab(pos, a, b, tab).tobytes() == ctx.fst_reduce(pos, a, b, win).tobytes(), (W, S)
+        assert ctx.het_reduce_tab(pos, g, tab).tobytes() == ctx.het_reduce(pos, g, win).tobytes(), (W, S)
+        rows_t, tot_t = ctx.dxy_reduce_tab(pos, p1, p2, n1, n2, 5, tab)
+        rows_h, tot_h = ctx.dxy_reduce(pos, p1, p2, n1, n2, 5, win)
+        assert rows_t.tobytes() == rows_h.tobytes() and tot_t.tobytes() == tot_h.tobytes(), (W, S)
+        tab.free()
