@@ -252,13 +252,12 @@ int main(int argc, char **argv) {
     }
     if (n_sites == 0) die("dxyWindow: the two MAF files share no site");
 
-    std::vector<pgt_win> win;
+    SiteWindows sw;  // fixed-site windows: on the host, or on the device when there are very many (-stepsize 1)
+    std::vector<pgt_win> &win = sw.win;
     if (W > 0) {
         size_t n_win = 0;
         if (fixedsite) {
-            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
-            win.resize(n_win);
-            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+            sw.build(runs, W, S, [&] { return device.get(); });
         } else {
             std::vector<uint32_t> chr_len(runs.name.size());
             for (size_t r = 0; r < runs.name.size(); ++r) {
@@ -275,19 +274,26 @@ int main(int argc, char **argv) {
     timer.lap("sync + table");
     pgt_ctx *ctx = device.get();
     timer.lap("wait for HIP");
-    std::vector<pgt_dxy_row> rows(win.size());
+    const size_t n_rows = sw.tab ? sw.n : win.size();
+    std::vector<pgt_dxy_row> rows(n_rows);
     pgt_dxy_total tot{};
-    if (on_device)
-        check(pgt_dxy_reduce_cols(ctx, m1.dev.col<uint32_t>(1), m1.dev.col<double>(5), m2.dev.col<double>(5), m1.dev.col<int32_t>(6),
-                                  m2.dev.col<int32_t>(6), n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
+    if (on_device) {  // frequencies and counts are on the GPU
+        pos = m1.dev.col<uint32_t>(1); p1 = m1.dev.col<double>(5); p2 = m2.dev.col<double>(5);
+        n1 = m1.dev.col<int32_t>(6); n2 = m2.dev.col<int32_t>(6);
+    }
+    if (sw.tab)
+        check(pgt_dxy_reduce_tab(ctx, pos, p1, p2, n1, n2, n_sites, minind, on_device, sw.tab, rows.data(), &tot), ctx);
+    else if (on_device)
+        check(pgt_dxy_reduce_cols(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
     else
         check(pgt_dxy_reduce(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
     timer.lap("gpu reduce");
 
     // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)
-    write_rows(win.size(), longest_name(runs) + 80, [&](size_t i, char *o) -> size_t {
+    write_rows(n_rows, longest_name(runs) + 80, [&](size_t i, char *o) -> size_t {
         if (!(rows[i].neff > 0 || !skip_missing)) return 0;
-        return put_row(o, runs.name[win[i].label_run], {rows[i].start, rows[i].end}, rows[i].sum, {rows[i].neff, rows[i].nskip});
+        return put_row(o, runs.name[sw.tab ? sw.label(i) : win[i].label_run], {rows[i].start, rows[i].end}, rows[i].sum,
+                       {rows[i].neff, rows[i].nskip});
     });
     // genome-wide line: stdout for the global run, stderr beside windows (dxyWindow.cpp:429-433)
     std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff,

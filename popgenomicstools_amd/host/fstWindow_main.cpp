@@ -77,25 +77,28 @@ int main(int argc, char **argv) {
         }
     }
 
-    size_t n_win = 0;
-    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+    SiteWindows sw;
+    sw.build(runs, W, S, [&] { return device.get(); });
+    const size_t n_win = sw.n;
     if (n_win == 0) return 0;
-    std::vector<pgt_win> win(n_win);
-    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
 
     timer.lap("window table");
     pgt_ctx *ctx = device.get();
     std::vector<pgt_fst_row> rows(n_win);
     timer.lap("wait for HIP");
-    if (on_device)
-        check(pgt_fst_reduce_cols(ctx, dtab.col<uint32_t>(1), dtab.col<double>(2), dtab.col<double>(3), n, win.data(), n_win, rows.data()), ctx);
+    const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
+    const double *a = on_device ? dtab.col<double>(2) : tab.a.data(), *b = on_device ? dtab.col<double>(3) : tab.b.data();
+    if (sw.tab)
+        check(pgt_fst_reduce_tab(ctx, pos, a, b, n, on_device, sw.tab, rows.data()), ctx);
+    else if (on_device)
+        check(pgt_fst_reduce_cols(ctx, pos, a, b, n, sw.win.data(), n_win, rows.data()), ctx);
     else
-        check(pgt_fst_reduce(ctx, tab.pos.data(), tab.a.data(), tab.b.data(), n, win.data(), n_win, rows.data()), ctx);
+        check(pgt_fst_reduce(ctx, pos, a, b, n, sw.win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");
 
     // chr start end mid fst nsites; %g == std::ostream default formatting (fstWindow.cpp:88)
     write_rows(n_win, longest_name(runs) + 80, [&](size_t i, char *o) {
-        return put_row(o, runs.name[win[i].label_run], {rows[i].start, rows[i].end, rows[i].mid}, rows[i].fst, {rows[i].n});
+        return put_row(o, runs.name[sw.label(i)], {rows[i].start, rows[i].end, rows[i].mid}, rows[i].fst, {rows[i].n});
     });
     finish(timer);
 }

@@ -726,6 +726,42 @@ inline bool ingest_on_device(pgt_ctx *ctx, const char *b, const char *e, const u
     return true;
 }
 
+// ---- the site-window table of a run: on the host, or — from 2^20 windows on — on the device -------------------
+// With `-stepsize 1` there is one window per site: 32 bytes of table per window that the host would fill and
+// upload only for the GPU to read once.  pgt_wintab_sites writes the same table in GPU memory from the run
+// lengths; the host keeps the index of every run's first window and finds a row's chromosome by bisection.
+struct SiteWindows {
+    std::vector<pgt_win> win;    // the table, when it lives on the host
+    pgt_wintab *tab = nullptr;   // ... or the device table
+    const uint64_t *first = nullptr;
+    size_t n_runs = 0, n = 0;
+    SiteWindows() = default;
+    SiteWindows(const SiteWindows &) = delete;
+    SiteWindows &operator=(const SiteWindows &) = delete;
+    ~SiteWindows() { if (tab) pgt_wintab_free(tab); }
+    uint32_t label(size_t i) const {
+        if (!tab) return win[i].label_run;
+        return (uint32_t)(std::upper_bound(first, first + n_runs + 1, (uint64_t)i) - first - 1);
+    }
+    // get_ctx: called only when the table goes to the device (it waits for HIP start-up)
+    template <class GetCtx>
+    void build(const Runs &runs, uint32_t W, uint32_t S, GetCtx &&get_ctx) {
+        check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n), nullptr);
+        const char *force = std::getenv("PGT_DEVICE_WINTAB");  // 0 / 1: never / always (tests); default by size
+        const bool on_device = force ? std::atoi(force) != 0 : n >= ((size_t)1 << 20);
+        if (n == 0) return;
+        if (on_device) {
+            pgt_ctx *ctx = get_ctx();
+            check(pgt_wintab_sites(ctx, runs.len.data(), runs.len.size(), W, S, &tab), ctx);
+            first = pgt_wintab_first(tab);
+            n_runs = runs.len.size();
+        } else {
+            win.resize(n);
+            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n), nullptr);
+        }
+    }
+};
+
 // Window size / step size as fstWindow.cpp:51-64 reads them (atoi); zero, negative or
 // non-numeric values are refused.  The reference only warns for a bad step and then crashes
 // (SURVEY.md §4 Q9); a step larger than the window crashes it too.  Here all of these exit 255.

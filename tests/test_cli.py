@@ -485,3 +485,41 @@ def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
             exact += 1
             total += 1
     assert exact >= total - 3  # fstWindow rows may differ in the sixth digit of a ratio; in practice none does
+
+
+@pytest.mark.gpu
+def test_cli_device_window_table_equals_host_table(hosts, tmp_path, oracle):
+    """From 2^20 windows on the hosts let the GPU write the site-window table (pgt_wintab_sites) and find the rows'
+    chromosome names from the run offsets.  PGT_DEVICE_WINTAB=1 forces that path on small inputs: reference-made
+    goldens, a multi-chromosome -stepsize 1 run and dxyWindow's fixed-site modes must print the same bytes as with
+    the host table (=0); one run above the threshold takes the path by itself."""
+    import synth
+    on, off = dict(os.environ, PGT_DEVICE_WINTAB="1"), dict(os.environ, PGT_DEVICE_WINTAB="0")
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::4]
+    for c in cases:
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        cmd = [hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])]
+        a, b = run(cmd, env=on), run(cmd, env=off)
+        assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (c["tool"], c["W"], c["S"])
+        tsv_equal(a.stdout, c["stdout"], 4)
+    k = helpers.load_golden("dxy_kat.json")
+    m1, m2 = tmp_path / "p1.mafs", tmp_path / "p2.mafs"
+    _write_maf(m1, k["header"], k["pop1"]); _write_maf(m2, k["header"], k["pop2"])
+    for c in k["cases"]:
+        if not c["fixedsite"]:
+            continue
+        cmd = [hosts["dxyWindow"], "-winsize", str(c["winsize"]), "-stepsize", str(c["stepsize"]), "-minind", str(k["minind"]),
+               "-fixedsite", "1", "-skip_missing", str(c["skip_missing"]), str(m1), str(m2)]
+        a = run(cmd, env=on)
+        assert a.returncode == 0 and a.stdout == c["stdout"] and a.stderr == c["stderr"]
+    # above the threshold: 1.2e6 sites in 5 chromosomes, one window per site
+    rng = np.random.default_rng(8)
+    n = 1_200_000
+    chr_ids, pos = synth.chromosomes(rng, n, 5, equal=False)
+    g = synth.het_column(rng, n)
+    h = tmp_path / "het.txt"
+    oracle.write_het_text(str(h), chr_ids, pos, g)
+    a = run([hosts["hetWindow"], str(h), "40", "1"], env=dict(os.environ, PGT_HOST_TIMING="1"))
+    b = run([hosts["hetWindow"], str(h), "40", "1"], env=off)
+    assert a.returncode == b.returncode == 0 and a.stdout == b.stdout and len(a.stdout.splitlines()) > n - 5 * 40
