@@ -275,7 +275,7 @@ int main(int argc, char **argv) {
     pgt_ctx *ctx = device.get();
     timer.lap("wait for HIP");
     const size_t n_rows = sw.tab ? sw.n : win.size();
-    std::vector<pgt_dxy_row> rows(n_rows);
+    RowArray<pgt_dxy_row> rows(n_rows);
     pgt_dxy_total tot{};
     if (on_device) {  // frequencies and counts are on the GPU
         pos = m1.dev.col<uint32_t>(1); p1 = m1.dev.col<double>(5); p2 = m2.dev.col<double>(5);

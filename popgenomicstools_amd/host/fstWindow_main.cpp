@@ -84,7 +84,7 @@ int main(int argc, char **argv) {
 
     timer.lap("window table");
     pgt_ctx *ctx = device.get();
-    std::vector<pgt_fst_row> rows(n_win);
+    RowArray<pgt_fst_row> rows(n_win);
     timer.lap("wait for HIP");
     const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
     const double *a = on_device ? dtab.col<double>(2) : tab.a.data(), *b = on_device ? dtab.col<double>(3) : tab.b.data();

@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
 
     timer.lap("window table");
     pgt_ctx *ctx = device.get();
-    std::vector<pgt_het_row> rows(n_win);
+    RowArray<pgt_het_row> rows(n_win);
     timer.lap("wait for HIP");
     const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
     const int8_t *g = on_device ? dtab.col<int8_t>(2) : tab.g.data();

@@ -726,6 +726,34 @@ inline bool ingest_on_device(pgt_ctx *ctx, const char *b, const char *e, const u
     return true;
 }
 
+// ---- the rows coming back from the GPU ----------------------------------------------------------------------
+// With one row per site (-stepsize 1) the row array is hundreds of megabytes: value-initialising it (std::vector)
+// and taking its page faults one at a time inside the device-to-host copy costs more than the kernels.  Here it is
+// left uninitialised — every row is written by the copy — and its pages are touched by all threads first.
+template <class T>
+struct RowArray {
+    std::unique_ptr<T[]> p;
+    size_t n;
+    explicit RowArray(size_t rows) : p(new T[rows ? rows : 1]), n(rows) {
+        const size_t bytes = rows * sizeof(T), page = 4096;
+        if (bytes < ((size_t)32 << 20)) return;
+        const int T_ = host_threads();
+        char *base = reinterpret_cast<char *>(p.get());
+        const size_t per = (bytes / (size_t)T_ + page - 1) / page * page;
+        std::vector<std::thread> th;
+        for (int t = 0; t < T_; ++t) {
+            const size_t lo = per * (size_t)t, hi = std::min(bytes, lo + per);
+            if (lo >= hi) break;
+            th.emplace_back([=] { for (size_t i = lo; i < hi; i += page) base[i] = 0; });
+        }
+        for (auto &x : th) x.join();
+    }
+    T *data() { return p.get(); }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 // ---- the site-window table of a run: on the host, or — from 2^20 windows on — on the device -------------------
 // With `-stepsize 1` there is one window per site: 32 bytes of table per window that the host would fill and
 // upload only for the GPU to read once.  pgt_wintab_sites writes the same table in GPU memory from the run
