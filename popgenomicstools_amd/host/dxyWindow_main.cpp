@@ -257,7 +257,7 @@ int main(int argc, char **argv) {
     if (W > 0) {
         size_t n_win = 0;
         if (fixedsite) {
-            sw.build(runs, W, S, [&] { return device.get(); });
+            sw.build(runs, W, S, [&] { return device.get(); }, &timer);
         } else {
             std::vector<uint32_t> chr_len(runs.name.size());
             for (size_t r = 0; r < runs.name.size(); ++r) {

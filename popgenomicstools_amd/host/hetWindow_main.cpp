@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
     }
 
     SiteWindows sw;
-    sw.build(runs, W, S, [&] { return device.get(); });
+    sw.build(runs, W, S, [&] { return device.get(); }, &timer);
     const size_t n_win = sw.n;
     if (n_win == 0) return 0;
 

@@ -773,13 +773,14 @@ struct SiteWindows {
     }
     // get_ctx: called only when the table goes to the device (it waits for HIP start-up)
     template <class GetCtx>
-    void build(const Runs &runs, uint32_t W, uint32_t S, GetCtx &&get_ctx) {
+    void build(const Runs &runs, uint32_t W, uint32_t S, GetCtx &&get_ctx, PhaseTimer *timer = nullptr) {
         check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n), nullptr);
         const char *force = std::getenv("PGT_DEVICE_WINTAB");  // 0 / 1: never / always (tests); default by size
         const bool on_device = force ? std::atoi(force) != 0 : n >= ((size_t)1 << 20);
         if (n == 0) return;
         if (on_device) {
             pgt_ctx *ctx = get_ctx();
+            if (timer) timer->lap("wait for HIP");
             check(pgt_wintab_sites(ctx, runs.len.data(), runs.len.size(), W, S, &tab), ctx);
             first = pgt_wintab_first(tab);
             n_runs = runs.len.size();
