@@ -782,8 +782,8 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
 // the window alone (whole-tile scans in a fixed lane order; the interior by range_partial), never on
 // which other windows share the wave: rows are bitwise independent of the grouping, hence of the
 // number of GPUs a table is sharded over.  Windows that start or end outside the group's two tiles take
-// the same three pieces from scans of their OWN tiles; windows too short to be split (A > B) and empty
-// windows take the plain range query of query_body — one by one, after the group's common work.
+// the same three pieces from scans of their OWN tiles, one by one, after the group's common work; windows
+// inside one tile (nothing to split) and windows of at most 32 sites are summed by their lane alone.
 // ------------------------------------------------------------------------------------------
 constexpr int kSlideTile = 128;
 constexpr int kSlideDirect = 32;  // windows of at most this many sites are summed by their lane alone, site by site
@@ -870,10 +870,12 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
         const uint64_t lo = wd.lo < hi ? wd.lo : hi;
         const uint64_t tl = lo / kSlideTile, th = hi / kSlideTile;
         const uint32_t offl = (uint32_t)(lo % kSlideTile), offh = (uint32_t)(hi % kSlideTile);
-        // Windows of a few sites (`-winsize 1 -stepsize 1`, the per-site mode dxyWindow.cpp:47 documents): the lane
-        // adds its own window's sites from left to right — the reference's own order (fstWindow.cpp:76-83) — instead
-        // of taking part in up to 64 wave-wide queries, one per window that does not reach a tile boundary.
-        const bool tiny = active && hi > lo && hi - lo <= (uint64_t)kSlideDirect;
+        // Windows of a few sites (`-winsize 1 -stepsize 1`, the per-site mode dxyWindow.cpp:47 documents) and windows
+        // that lie inside one 128-site tile (no boundary to split them at): the lane adds its own window's sites from
+        // left to right — the reference's own order (fstWindow.cpp:76-83) — instead of taking part in up to 64
+        // wave-wide queries, one per such window.
+        const uint64_t A = offl ? (tl + 1) * kSlideTile : lo, B = th * kSlideTile;  // first / last tile boundary inside [lo, hi]
+        const bool tiny = active && hi > lo && (hi - lo <= (uint64_t)kSlideDirect || A > B);  // A > B: inside one tile (< 128 sites)
         if (tiny) {
             Node acc = none;
             for (uint64_t i = lo; i < hi; ++i) node_add(acc, Tr::leaf(c, i));
@@ -900,7 +902,6 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
             for (int k = 0; k < 2; ++k)
                 scan_tile(side, (side ? th0 : tl0) + (uint64_t)k, span + (side * 2 + k) * kSlideTile);
         // the wave's own LDS rows: LDS operations of one wave complete in order, no barrier needed
-        const uint64_t A = offl ? (tl + 1) * kSlideTile : lo, B = th * kSlideTile;
         const bool fast = active && !tiny && hi > lo && tl - tl0 <= 1 && th - th0 <= 1 && A <= B;
         Node left = none, right = none;
         if (fast && offl) left = span[(0 * 2 + (int)(tl - tl0)) * kSlideTile + offl];
