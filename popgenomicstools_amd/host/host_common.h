@@ -31,6 +31,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -217,7 +218,12 @@ class Text {
             munmap(zmap, zlen);
             return 0;
         }
-        big_.reset(new char[total ? total : 1]);  // not value-initialised: the inflating threads touch the pages first
+        try {
+            big_.reset(new char[total ? total : 1]);  // not value-initialised: the inflating threads touch the pages first
+        } catch (const std::bad_alloc &) {  // members announcing more text than this machine can hold
+            munmap(zmap, zlen);
+            return -1;
+        }
         unsigned T = std::thread::hardware_concurrency();
         T = T ? (T > 32 ? 32 : T) : 1;
         if (const char *e = std::getenv("PGT_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
