@@ -939,7 +939,8 @@ def test_entry_points_leave_the_callers_device_alone(pgt, ctx):
 # sliding query (pgt_set_window_step <= 32)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("W,S", [(1, 1), (2, 1), (5, 2), (127, 1), (128, 1), (129, 3), (300, 1), (5_000, 1), (5_000, 7),
-                                 (50_000, 1), (50_000, 32), (1_000, 31)])
+                                 (50_000, 1), (50_000, 32), (1_000, 31),
+                                 (32, 1), (33, 1), (64, 3), (100, 1), (100, 32)])  # around the per-lane direct path (<= 32 sites, or inside one tile)
 def test_sliding_query_vs_oracle(pgt, ctx, oracle, W, S):
     """S << W: the host API derives the step hint from the table and takes the sliding query; every
     statistic against the oracle (ints exact, floats 1e-9), on ragged chromosome layouts (short
