@@ -787,31 +787,57 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
 // ------------------------------------------------------------------------------------------
 constexpr int kSlideTile = 128;
 constexpr int kSlideDirect = 32;  // windows of at most this many sites are summed by their lane alone, site by site
-template <class Node>
-__device__ __forceinline__ Node node_from_lane(const Node &v, int src_lane) {
+// Exclusive scans over the lanes in a fixed order; UP = sum of the lanes ABOVE, else of the lanes BELOW.
+// Inside each 16-lane row: four Hillis-Steele steps with DPP row shifts (lanes without a source add the
+// identity); then every lane adds the totals of the rows before (after) its own, read from lanes 15/31/47
+// (0/16/32/48 for UP) into scalar registers and added nearest row first; a one-lane wave shift turns inclusive
+// into exclusive.  All of it on the VALU: the first version's 28 ds_bpermute per scan went through LDS, which
+// the scan tables of this kernel need for themselves.  (Nodes of the sliding query have an all-zero identity.)
+template <class Node, int CTRL>
+__device__ __forceinline__ Node node_dpp(const Node &v) {  // lanes the DPP control gives no source keep 0 = the identity
     constexpr int kWords = sizeof(Node) / 4;
-    uint32_t w[kWords];
+    int w[kWords];
     __builtin_memcpy(w, &v, sizeof(Node));
 #pragma unroll
-    for (int k = 0; k < kWords; ++k) w[k] = (uint32_t)__shfl((int)w[k], src_lane, kWave);
+    for (int k = 0; k < kWords; ++k) w[k] = __builtin_amdgcn_update_dpp(0, w[k], CTRL, 0xF, 0xF, false);
     Node o;
     __builtin_memcpy(&o, w, sizeof(Node));
     return o;
 }
-// exclusive scans over the lanes in a fixed (Hillis-Steele) order; `up` = sum of the lanes ABOVE
+template <class Node>
+__device__ __forceinline__ Node node_readlane(const Node &v, int src_lane) {  // wave-uniform result
+    constexpr int kWords = sizeof(Node) / 4;
+    int w[kWords];
+    __builtin_memcpy(w, &v, sizeof(Node));
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) w[k] = __builtin_amdgcn_readlane(w[k], src_lane);
+    Node o;
+    __builtin_memcpy(&o, w, sizeof(Node));
+    return o;
+}
 template <class Node, bool UP>
 __device__ __forceinline__ Node lane_scan_exclusive(Node v, int lane) {
     const Node none = node_identity<Node>();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int src = UP ? lane + d : lane - d;
-        const Node t = node_from_lane(v, src & (kWave - 1));
-        Node add = (src >= 0 && src < kWave) ? t : none;
-        node_add(v, add);
+    // inclusive scan inside the row: row_shl:n = 0x100 + n reads lane + n, row_shr:n = 0x110 + n reads lane - n
+    node_add(v, UP ? node_dpp<Node, 0x101>(v) : node_dpp<Node, 0x111>(v));
+    node_add(v, UP ? node_dpp<Node, 0x102>(v) : node_dpp<Node, 0x112>(v));
+    node_add(v, UP ? node_dpp<Node, 0x104>(v) : node_dpp<Node, 0x114>(v));
+    node_add(v, UP ? node_dpp<Node, 0x108>(v) : node_dpp<Node, 0x118>(v));
+    // totals of the four rows (the lane where the row's inclusive scan ends)
+    const Node r0 = node_readlane(v, UP ? 0 : 15), r1 = node_readlane(v, UP ? 16 : 31), r2 = node_readlane(v, UP ? 32 : 47),
+               r3 = node_readlane(v, UP ? 48 : 63);
+    const int row = lane >> 4;
+    if (UP) {  // rows above mine, nearest first
+        node_add(v, row < 1 ? r1 : none);
+        node_add(v, row < 2 ? r2 : none);
+        node_add(v, row < 3 ? r3 : none);
+    } else {   // rows below mine, nearest first
+        node_add(v, row > 2 ? r2 : none);
+        node_add(v, row > 1 ? r1 : none);
+        node_add(v, row > 0 ? r0 : none);
     }
-    const int nb = UP ? lane + 1 : lane - 1;  // inclusive -> exclusive: take the neighbour's inclusive value
-    const Node t = node_from_lane(v, nb & (kWave - 1));
-    return (nb >= 0 && nb < kWave) ? t : none;
+    // inclusive -> exclusive: the neighbour's inclusive value (wave_shl:1 = 0x130 reads lane + 1, wave_shr:1 = 0x138 lane - 1)
+    return UP ? node_dpp<Node, 0x130>(v) : node_dpp<Node, 0x138>(v);
 }
 
 template <class Tr>
