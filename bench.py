@@ -10,15 +10,22 @@ build the range tree (the streaming pass over a,b: 16 B/site) + answer every win
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment) starts the N ranks itself:
+the parent — which never touches the GPU and imports neither torch nor the library — runs the second
+command above as a CHILD process on a free port of 127.0.0.1, relays its output and exits with its code.
+
 N > 1 (one process per GPU): the window table is built once (identical on every rank) and cut by
 pgt_plan_shards into N contiguous blocks; rank r materialises ONLY its own site range [site_lo,
 site_hi) of the genome (counter-based generator keyed on the global site index, halo <= one window)
-and reduces its block.  Rows reach rank 0 either by peer stores over xGMI into rank 0's row buffer
-(no per-step collective; default when every rank can map it) or by an asynchronous double-buffered
-RCCL gather.  STRONG scaling: total work is fixed at --sites; value = --sites x steps / max-over-ranks
-time.  After the timed region rank 0 rebuilds the whole genome, runs the single-GPU scan and demands
-the assembled multi-GPU table to be bitwise equal ("rows_check"); the table's SHA-256 ("rows_sha256")
-is the same for every N.  --scaling weak instead gives every rank --sites sites (genome = N x --sites).
+and reduces its block.  Rows reach rank 0 by an asynchronous double-buffered RCCL gather, or by peer
+stores over xGMI into rank 0's row buffer (no per-step collective).  With --exchange auto (default) BOTH
+transports are timed and each assembled table is checked; "value" is the gather's (the transport
+north_star names) unless the peer-store run was verified bitwise in this very run AND was faster;
+both timings are in "extra" (exchange_gather / exchange_peer).  STRONG scaling: total work is fixed at
+--sites; value = --sites x steps / max-over-ranks time.  After each timed region rank 0 rebuilds the whole
+genome (once), runs the single-GPU scan and demands the assembled multi-GPU table to be bitwise equal
+("rows_check"); the table's SHA-256 ("rows_sha256") is the same for every N.  --scaling weak instead gives
+every rank --sites sites (genome = N x --sites).
 
 `--workload pairs --sites 1e8 --chroms 20` runs BASELINE configs[4] the same way: all 28 pairs of 8 populations
 batched in one launch per step over one window table, site ranges sharded over the N GPUs, the 28 x windows
@@ -32,10 +39,58 @@ import argparse
 import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
 import time
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sites", type=float, default=1e9, help="sites of the genome (strong scaling) or per GPU (--scaling weak)")
+    ap.add_argument("--chroms", type=int, default=40, help="chromosomes of the genome (per GPU with --scaling weak)")
+    ap.add_argument("--winsize", type=int, default=50_000)
+    ap.add_argument("--stepsize", type=int, default=10_000)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--exchange", choices=["auto", "peer", "gather"], default="auto",
+                    help="how rows reach rank 0 when N > 1: auto = time the RCCL gather AND (where every rank can map the "
+                         "buffer) peer stores, report both, headline = gather unless peer was verified and faster")
+    ap.add_argument("--cpu-sites", type=float, default=5e7,
+                    help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
+    ap.add_argument("--workload", choices=["fst", "pairs"], default="fst",
+                    help="fst = the headline 2-population scan (default); pairs = BASELINE configs[4]: all --pairs population pairs "
+                         "batched over one window table (use --sites 1e8 --chroms 20), sharded by site range like the headline")
+    ap.add_argument("--pairs", type=int, default=28, help="population pairs of --workload pairs (8 populations = 28)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a child process group.
+    Nothing in this process has touched the GPU (no HIP call, torch not even imported), and the ranks are
+    CHILDREN (subprocess), never an exec of this process."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode  # stdout / stderr are inherited: rank 0's JSON line passes through
+
+
+if __name__ == "__main__":
+    _args = parse_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(_args))
 
 import numpy as np
 import torch
@@ -46,7 +101,7 @@ sys.path.insert(0, ROOT)
 
 import popgenomicstools_amd as pgt  # noqa: E402
 from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, FST_ROW_DTYPE, HET_ROW_DTYPE, PGT_STAT_DXY, PGT_STAT_FST,  # noqa: E402
-                                       PGT_STAT_HET, WIN_DTYPE)
+                                       PGT_STAT_HET, WIN_DTYPE, PgtError)
 from popgenomicstools_amd.distributed import RowExchange  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
@@ -210,28 +265,7 @@ def extra_configs(ctx, dev, W, S, tree_pool):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=float, default=1e9, help="sites of the genome (strong scaling) or per GPU (--scaling weak)")
-    ap.add_argument("--chroms", type=int, default=40, help="chromosomes of the genome (per GPU with --scaling weak)")
-    ap.add_argument("--winsize", type=int, default=50_000)
-    ap.add_argument("--stepsize", type=int, default=10_000)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--exchange", choices=["auto", "peer", "gather"], default="auto",
-                    help="how rows reach rank 0 when N > 1 (auto = peer stores if every rank can map the buffer, else gather)")
-    ap.add_argument("--cpu-sites", type=float, default=5e7,
-                    help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--headline-only", action="store_true",
-                    help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
-    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
-    ap.add_argument("--workload", choices=["fst", "pairs"], default="fst",
-                    help="fst = the headline 2-population scan (default); pairs = BASELINE configs[4]: all --pairs population pairs "
-                         "batched over one window table (use --sites 1e8 --chroms 20), sharded by site range like the headline")
-    ap.add_argument("--pairs", type=int, default=28, help="population pairs of --workload pairs (8 populations = 28)")
-    args = ap.parse_args()
+    args = parse_args()
     pairs_mode = args.workload == "pairs"
     n_tables = args.pairs if pairs_mode else 1
 
@@ -291,21 +325,20 @@ def main():
         if want_extra else n_tables * ctx.tree_bytes(PGT_STAT_FST, n)
     tree = torch.empty(tree_bytes, dtype=torch.uint8, device=dev)
     counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64) * n_tables  # rows per rank and step
-    ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=args.exchange, coll_device=coll_dev,
-                     tables=n_tables)
+    ctx.set_window_step(S)  # the query strategy follows (W, S) of the whole table, not a rank's slice of it
 
-    def step():
-        out = ex.begin()
-        scan(mycols, win_d, out, tree)
-        ex.end()
+    def timed_region(ex):
+        def step():
+            out = ex.begin()
+            scan(mycols, win_d, out, tree)
+            ex.end()
 
-    def fence():
-        ex.flush()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def fence():
+            ex.flush()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def timed_region():
         for _ in range(args.warmup):
             step()
         fence()
@@ -313,18 +346,14 @@ def main():
         for _ in range(args.steps):
             step()
         fence()
-        dt = time.perf_counter() - t0
+        dt_ = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            t = torch.tensor([dt_], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            dt_ = float(t.item())
+        return dt_
 
-    dt = timed_region()
-    table = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
-
-    # --- N > 1: the assembled table must be the single-GPU table, bit for bit ------------------
-    rows_check, sha, rows = None, None, None
+    # --- N > 1: every assembled table must be the single-GPU table, bit for bit -----------------
     single = {}
 
     def single_gpu_table():
@@ -335,38 +364,69 @@ def main():
             fout = torch.empty(n_tables * win.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             scan(fcols, windows_to_device(win, dev), fout, ftree)
             single["t"] = fout.cpu().numpy().tobytes()
+            del fcols, ftree, fout
+            torch.cuda.empty_cache()
         return single["t"]
 
     can_verify = world > 1 and not args.no_verify and (args.scaling == "strong" or n_total <= 2_000_000_000)
-    if world > 1:
-        verdict = torch.zeros(1, dtype=torch.int32, device=coll_dev)
-        if rank == 0 and can_verify:
-            verdict[0] = 0 if single_gpu_table() == table.tobytes() else 1
-        dist.broadcast(verdict, src=0)
-        bad = int(verdict.item()) != 0
-        if bad and ex.mode == "peer":
-            # peer stores did not deliver the right table on this machine: measure the gather transport instead
-            if rank == 0:
-                print("bench.py: peer-store table differs from the single-GPU table; re-running with the RCCL gather",
-                      file=sys.stderr, flush=True)
-            ex.close()
-            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode="gather", coll_device=coll_dev,
-                             tables=n_tables)
-            dt = timed_region()
-            table = ex.finish()
-            if rank == 0:
-                verdict[0] = 0 if single_gpu_table() == table.tobytes() else 1
+
+    def run_transport(mode):
+        """One row transport: timed region + the table of its last step + the bitwise check.  Collective."""
+        try:
+            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=mode, coll_device=coll_dev, tables=n_tables)
+        except PgtError as e:  # peer: the buffer cannot be mapped by every rank (decided collectively)
+            return {"mode": mode, "available": False, "why": str(e)}
+        dt_ = timed_region(ex)
+        table_ = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
+        res = {"mode": ex.mode, "available": True, "dt": dt_, "table": table_, "verified": None}
+        if world > 1:
+            verdict = torch.zeros(1, dtype=torch.int32, device=coll_dev)
+            if rank == 0 and can_verify:
+                verdict[0] = 0 if single_gpu_table() == table_.tobytes() else 1
             dist.broadcast(verdict, src=0)
-            bad = int(verdict.item()) != 0
-        if bad:
-            raise SystemExit("bench.py: the multi-GPU table differs from the single-GPU table of the same genome")
-        if rank == 0:
-            rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
-                          ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
+            res["verified"] = (int(verdict.item()) == 0) if can_verify else None
+        ex.close()
+        return res
+
+    if world == 1:
+        runs = [run_transport("local")]
+    else:
+        runs = [run_transport(m) for m in (("gather", "peer") if args.exchange == "auto" else (args.exchange,))]
+    usable = [r for r in runs if r["available"]]
+    if not usable:
+        raise SystemExit("bench.py: --exchange peer, but the row buffer cannot be mapped by every rank: " + runs[0]["why"])
+    bad = [r["mode"] for r in usable if r["verified"] is False]
+    if bad and rank == 0:
+        print(f"bench.py: the table assembled by {bad} differs from the single-GPU table of the same genome", file=sys.stderr, flush=True)
+    # headline: the gather, unless peer stores were verified in this run and were faster; an unverifiable run
+    # (--no-verify, genome too large to rebuild) never promotes peer stores
+    good = [r for r in usable if r["verified"] is not False]
+    if not good:
+        raise SystemExit("bench.py: no row transport delivered the single-GPU table")
+    head = good[0]
+    for r in good[1:]:
+        if r["mode"] == "peer" and r["verified"] and r["dt"] < head["dt"]:
+            head = r
+    dt, table, head_mode = head["dt"], head["table"], head["mode"]
+    rows_check, sha, rows = None, None, None
+    if world > 1 and rank == 0:
+        rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
+                      ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
     if rank == 0:
         sha = hashlib.sha256(table.tobytes()).hexdigest()
         rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)
         assert rows.size == n_tables * win.size  # table-major: pair 0's rows come first
+    exchange_report = {}
+    for r in runs:
+        key = "exchange_" + r["mode"]
+        if not r["available"]:
+            exchange_report[key] = {"available": False, "why": r["why"]}
+        else:
+            exchange_report[key] = {"ms_per_step": r["dt"] / args.steps * 1e3, "sites_per_s": float(n_total) * args.steps / r["dt"],
+                                    "rows_check": ("bitwise equal" if r["verified"] else "DIFFERS") if r["verified"] is not None else "not verified",
+                                    "headline": r is head}
+    if bad and args.exchange != "auto":
+        raise SystemExit("bench.py: the multi-GPU table differs from the single-GPU table of the same genome")
 
     # --- roofline of the dominant kernel: HIP events on the launch stream, around the build pass only
     scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
@@ -391,10 +451,13 @@ def main():
             assert rows["n"][i] == hi - lo and rows["start"][i] == (int(pos[lo]) & 0xFFFFFFFF)
 
     extra, cpu = {}, None
+    if world > 1:
+        extra.update(exchange_report)
     if rank == 0 and world == 1 and not pairs_mode:
         if not args.headline_only:
             extra = extra_configs(ctx, dev, W, S, tree)
             ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
+            ctx.set_window_step(S)
         if not args.no_cpu:
             cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra)
 
@@ -419,7 +482,7 @@ def main():
                                    + f" in {genome.run_len.size} chromosomes"
                                    + (f" sharded x{world} by window blocks (pgt_plan_shards)" if world > 1 else "")
                                    + f", window {W} sites / step {S} sites, {win.size} windows, columns resident in HBM"
-                                   + (f", rows to rank 0 by {'peer stores over xGMI' if ex.mode == 'peer' else 'async RCCL gather'}"
+                                   + (f", rows to rank 0 by {'peer stores over xGMI' if head_mode == 'peer' else 'async RCCL gather'}"
                                       if world > 1 else ""),
                        "baseline_config": ("BASELINE configs[3] (10^9-site fstWindow scan sharded over the GPUs; at N=1 the same genome "
                                            "on one GPU: the size north_star's roofline target is quoted on); configs[1], [2], [4] in `extra`"
@@ -427,7 +490,7 @@ def main():
                                            "BASELINE configs[4]: fstWindow all-pairs of 8 populations x 10^8 sites, pairs batched in one launch, "
                                            "site ranges sharded over the GPUs"),
                        "sites_total": n_total, "sites_resident_per_gpu": per_gpu, "winsize": W, "stepsize": S,
-                       "windows": int(win.size), "seed": SEED, "row_exchange": ex.mode,
+                       "windows": int(win.size), "seed": SEED, "row_exchange": head_mode,
                        "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
                                       if world > 1 else "single GPU"},
             "rows_sha256": sha,
@@ -441,7 +504,6 @@ def main():
             "extra": extra,
         }
         print(json.dumps(line), flush=True)
-    ex.close()
     ctx.close()
     if world > 1:
         dist.barrier()

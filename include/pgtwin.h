@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PGT_ABI_VERSION 3
+#define PGT_ABI_VERSION 4
 
 enum {
     PGT_OK = 0,
@@ -116,39 +116,45 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
 /* Every pointer is a DEVICE pointer on ctx's device; f64 columns must be 16-byte aligned.
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).  `tree` is caller
  * workspace of at least pgt_tree_bytes(stat, n) bytes, 256-byte aligned: it receives the
- * radix-64 range tree and may be reused by later calls. */
+ * radix-64 range tree and may be reused by later calls.
+ * ABI 4: every row output carries its CAPACITY in bytes (`out_bytes`, right after the pointer, as
+ * `tree_bytes` follows `tree`): a call whose rows would not fit returns PGT_EARG before anything is
+ * launched.  In the multi-GPU peer mode `out` points into ANOTHER GPU's row buffer (pgt_rowbuf_open),
+ * where an overrun would be a silent cross-device write. */
 enum { PGT_STAT_FST = 0, PGT_STAT_HET = 1, PGT_STAT_DXY = 2, PGT_STAT_EXT = 3 };
 size_t pgt_tree_bytes(int stat, uint64_t n_sites);
 
 int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b,
                        uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
-                       void *tree, size_t tree_bytes, void *stream);
+                       size_t out_bytes, void *tree, size_t tree_bytes, void *stream);
 int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n,
-                       const pgt_win *win, uint64_t n_win, pgt_het_row *out, void *tree,
-                       size_t tree_bytes, void *stream);
+                       const pgt_win *win, uint64_t n_win, pgt_het_row *out, size_t out_bytes,
+                       void *tree, size_t tree_bytes, void *stream);
 /* tot: device pointer to one pgt_dxy_total, or NULL. */
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
                        const int32_t *n1, const int32_t *n2, uint64_t n, int minind,
-                       const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot,
-                       void *tree, size_t tree_bytes, void *stream);
+                       const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, size_t out_bytes,
+                       pgt_dxy_total *tot, void *tree, size_t tree_bytes, void *stream);
 
 /* dxyWindow + hetWindow of two genotype columns over ONE position column and ONE window table
  * (BASELINE config 3): one build launch streams all six columns (26 B/site), one query launch
  * answers the three tables.  tree must hold pgt_tree_bytes(PGT_STAT_DXY, n) +
- * 2 * pgt_tree_bytes(PGT_STAT_HET, n) bytes.  Rows equal those of the separate calls bit for bit. */
+ * 2 * pgt_tree_bytes(PGT_STAT_HET, n) bytes.  Rows equal those of the separate calls bit for bit.
+ * het_out_bytes is the capacity of EACH of the two genotype tables. */
 int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
                            const int32_t *n1, const int32_t *n2, const int8_t *g1, const int8_t *g2,
                            uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
-                           pgt_dxy_row *dxy_out, pgt_dxy_total *tot, pgt_het_row *het_out1,
-                           pgt_het_row *het_out2, void *tree, size_t tree_bytes, void *stream);
+                           pgt_dxy_row *dxy_out, size_t dxy_out_bytes, pgt_dxy_total *tot,
+                           pgt_het_row *het_out1, pgt_het_row *het_out2, size_t het_out_bytes,
+                           void *tree, size_t tree_bytes, void *stream);
 
 /* Batched population pairs sharing one position column and one window table (BASELINE
  * config 5): a[p], b[p] are HOST arrays of n_pairs DEVICE column pointers; out holds
  * n_pairs * n_win rows, pair-major; tree holds n_pairs trees (n_pairs * pgt_tree_bytes). */
 int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *a,
                              const double *const *b, uint32_t n_pairs, uint64_t n,
-                             const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
-                             size_t tree_bytes, void *stream);
+                             const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes,
+                             void *tree, size_t tree_bytes, void *stream);
 
 /* ---- allele-frequency front end ------------------------------------------ */
 /* Population allele frequencies -> Reynolds / Weir-Cockerham variance components exactly as WCFst()
@@ -165,7 +171,7 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
 size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites);
 int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
                           uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
-                          void *tree, size_t tree_bytes, void *stream);
+                          size_t out_bytes, void *tree, size_t tree_bytes, void *stream);
 
 /* ---- ihsWindow / xpehhWindow: extreme score in non-overlapping bp windows ---- */
 /* Replaces the window bookkeeping and per-window scan of ihsWindow.cpp:123-221 and
@@ -194,7 +200,7 @@ int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, u
 /* device-resident form; tree: pgt_tree_bytes(PGT_STAT_EXT, n) bytes */
 int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode,
                            double cutoff, const pgt_win *win, uint64_t n_win, pgt_ext_row *out,
-                           void *tree, size_t tree_bytes, void *stream);
+                           size_t out_bytes, void *tree, size_t tree_bytes, void *stream);
 
 /* ---- performance hint ------------------------------------------------------------------- */
 /* Longest window (in sites) the following *_dev calls will be asked for; 0 (the default) = unknown.
@@ -255,6 +261,11 @@ int pgt_rowbuf_create(pgt_ctx *ctx, size_t bytes, void **dev_ptr, pgt_ipc_handle
 int pgt_rowbuf_open(pgt_ctx *ctx, const pgt_ipc_handle *handle, void **dev_ptr);
 int pgt_rowbuf_close(pgt_ctx *ctx, void *dev_ptr, int owner);
 int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, void *stream);
+/* Self-test of a mapping before it is trusted: a kernel on ctx's device stores the 8-byte words
+ * splitmix64(seed + i), i = 0 .. bytes/8 - 1, to dev_ptr with the same plain global stores the query kernels
+ * use for their rows (asynchronous on `stream`; bytes a multiple of 8, dev_ptr 8-byte aligned).  Every rank
+ * fills its slice of the shared buffer, the owner reads it back (pgt_rowbuf_read) and compares. */
+int pgt_rowbuf_fill(pgt_ctx *ctx, void *dev_ptr, size_t bytes, uint64_t seed, void *stream);
 
 /* ---- device-side text ingest ------------------------------------------------ */
 /* Replaces the per-line text parse of the reference's streaming loops (fstWindow.cpp:123-146 `chr pos a b`,
@@ -288,12 +299,12 @@ typedef struct pgt_ingest pgt_ingest;
 /* reductions over DEVICE columns (pgt_ingest_column) with the window table and the rows in HOST memory:
  * the host-buffer entry points minus the column upload; synchronous */
 int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, const double *d_b, uint64_t n,
-                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out);
+                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes);
 int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, uint64_t n,
-                        const pgt_win *win, uint64_t n_win, pgt_het_row *out);
+                        const pgt_win *win, uint64_t n_win, pgt_het_row *out, size_t out_bytes);
 int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2,
                         const int32_t *d_n1, const int32_t *d_n2, uint64_t n, int minind,
-                        const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot);
+                        const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, size_t out_bytes, pgt_dxy_total *tot);
 /* device column of token `token` -> host (bytes <= rows * element size, else PGT_EARG) */
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
@@ -312,7 +323,8 @@ void pgt_ingest_free(pgt_ingest *ing);
  * row i carries the name of the run r with first[r] <= i < first[r+1] (pgt_win.label_run of the host table).
  * pgt_wintab_device: the table itself, a DEVICE pointer usable as `win` of the *_dev calls.
  * *_reduce_tab: the host-buffer entry points (cols_on_device = 0: pos / a / b ... are host arrays, uploaded here)
- * or the *_reduce_cols ones (cols_on_device = 1) over such a table; rows come back to HOST memory; synchronous. */
+ * or the *_reduce_cols ones (cols_on_device = 1) over such a table; rows come back to HOST memory (out_bytes =
+ * capacity of `out`, at least pgt_wintab_size rows); synchronous. */
 typedef struct pgt_wintab pgt_wintab;
 int pgt_wintab_sites(pgt_ctx *ctx, const uint64_t *run_len, size_t n_runs, uint32_t W, uint32_t S, pgt_wintab **out);
 uint64_t pgt_wintab_size(const pgt_wintab *tab);
@@ -320,12 +332,12 @@ const uint64_t *pgt_wintab_first(const pgt_wintab *tab);
 const pgt_win *pgt_wintab_device(const pgt_wintab *tab);
 void pgt_wintab_free(pgt_wintab *tab);
 int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n, int cols_on_device,
-                       const pgt_wintab *tab, pgt_fst_row *out);
+                       const pgt_wintab *tab, pgt_fst_row *out, size_t out_bytes);
 int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, int cols_on_device,
-                       const pgt_wintab *tab, pgt_het_row *out);
+                       const pgt_wintab *tab, pgt_het_row *out, size_t out_bytes);
 int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                        const int32_t *n2, uint64_t n, int minind, int cols_on_device, const pgt_wintab *tab,
-                       pgt_dxy_row *out, pgt_dxy_total *tot);
+                       pgt_dxy_row *out, size_t out_bytes, pgt_dxy_total *tot);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpgtwin.so")
 
+PGT_ABI_VERSION = 4
 PGT_OK, PGT_EARG, PGT_ECAP, PGT_EDEVICE, PGT_EDOMAIN, PGT_ENOMEM = range(6)
 PGT_WIN_COORDS = 1
 PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY, PGT_STAT_EXT = 0, 1, 2, 3
@@ -44,7 +45,7 @@ SYMBOLS = [
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
-    "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read",
+    "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read", "pgt_rowbuf_fill",
     "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
     "pgt_wintab_sites", "pgt_wintab_size", "pgt_wintab_first", "pgt_wintab_device", "pgt_wintab_free",
     "pgt_fst_reduce_tab", "pgt_het_reduce_tab", "pgt_dxy_reduce_tab",
@@ -90,20 +91,20 @@ def load() -> C.CDLL:
     lib.pgt_build_windows_bp.argtypes = [vp, vp, vp, sz, u32, u32, vp, sz, C.POINTER(sz)]
     lib.pgt_build_windows_extreme.argtypes = [vp, vp, vp, sz, u32, vp, sz, C.POINTER(sz)]
     lib.pgt_extreme_reduce.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp]
-    lib.pgt_extreme_reduce_dev.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp, vp, sz, vp]
+    lib.pgt_extreme_reduce_dev.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp, sz, vp, sz, vp]
     lib.pgt_fst_reduce.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp]
     lib.pgt_het_reduce.argtypes = [vp, vp, vp, u64, vp, u64, vp]
     lib.pgt_dxy_reduce.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp]
     lib.pgt_tree_bytes.restype = sz
     lib.pgt_tree_bytes.argtypes = [i32, u64]
-    lib.pgt_fst_reduce_dev.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp, vp, sz, vp]
-    lib.pgt_het_reduce_dev.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, sz, vp]
-    lib.pgt_dxy_reduce_dev.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp, vp, sz, vp]
-    lib.pgt_fst_reduce_pairs_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
-    lib.pgt_dxy_het_reduce_dev.argtypes = [vp] * 8 + [u64, i32, vp, u64, vp, vp, vp, vp, vp, sz, vp]
+    lib.pgt_fst_reduce_dev.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp, sz, vp, sz, vp]
+    lib.pgt_het_reduce_dev.argtypes = [vp, vp, vp, u64, vp, u64, vp, sz, vp, sz, vp]
+    lib.pgt_dxy_reduce_dev.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, sz, vp, vp, sz, vp]
+    lib.pgt_fst_reduce_pairs_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, sz, vp, sz, vp]
+    lib.pgt_dxy_het_reduce_dev.argtypes = [vp] * 8 + [u64, i32, vp, u64, vp, sz, vp, vp, vp, sz, vp, sz, vp]
     lib.pgt_af_tree_bytes.restype = sz
     lib.pgt_af_tree_bytes.argtypes = [u32, u64]
-    lib.pgt_fst_af_reduce_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, vp, sz, vp]
+    lib.pgt_fst_af_reduce_dev.argtypes = [vp, vp, vp, vp, u32, u64, vp, u64, vp, sz, vp, sz, vp]
     lib.pgt_set_max_window.argtypes = [vp, u64]
     lib.pgt_set_window_step.argtypes = [vp, u64]
     lib.pgt_set_profiling.argtypes = [vp, i32]
@@ -114,9 +115,10 @@ def load() -> C.CDLL:
     lib.pgt_rowbuf_open.argtypes = [vp, vp, C.POINTER(vp)]
     lib.pgt_rowbuf_close.argtypes = [vp, vp, i32]
     lib.pgt_rowbuf_read.argtypes = [vp, vp, vp, sz, vp]
-    lib.pgt_fst_reduce_cols.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp]
-    lib.pgt_het_reduce_cols.argtypes = [vp, vp, vp, u64, vp, u64, vp]
-    lib.pgt_dxy_reduce_cols.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, vp]
+    lib.pgt_rowbuf_fill.argtypes = [vp, vp, sz, u64, vp]
+    lib.pgt_fst_reduce_cols.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp, sz]
+    lib.pgt_het_reduce_cols.argtypes = [vp, vp, vp, u64, vp, u64, vp, sz]
+    lib.pgt_dxy_reduce_cols.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, sz, vp]
     lib.pgt_ingest_download.argtypes = [vp, vp, i32, vp, sz]
     lib.pgt_ingest_text.argtypes = [vp, vp, sz, vp, i32, C.POINTER(vp)]
     lib.pgt_ingest_rows.restype = u64
@@ -138,11 +140,13 @@ def load() -> C.CDLL:
     lib.pgt_wintab_device.argtypes = [vp]
     lib.pgt_wintab_free.restype = None
     lib.pgt_wintab_free.argtypes = [vp]
-    lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp]
-    lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp]
-    lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, vp]
+    lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp, sz]
+    lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp, sz]
+    lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, vp]
     for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
         getattr(lib, name)
+    if lib.pgt_abi_version() != PGT_ABI_VERSION:  # argument lists changed between ABI versions: never call across them
+        raise RuntimeError(f"libpgtwin.so has ABI version {lib.pgt_abi_version()}, this binding is written for {PGT_ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -38,6 +38,14 @@ int hip_check(pgt_ctx *ctx, hipError_t e, const char *what) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ABI 4: every row output carries its capacity; refuse before anything is launched
+int room_check(pgt_ctx *ctx, const char *who, uint64_t rows, size_t row_bytes, size_t out_bytes) {
+    if (rows != 0 && (rows > SIZE_MAX / row_bytes || rows * row_bytes > out_bytes))
+        return ctx_fail(ctx, PGT_EARG, std::string(who) + ": the rows do not fit the output buffer (" + std::to_string(rows) + " rows of " +
+                                           std::to_string(row_bytes) + " bytes, capacity " + std::to_string(out_bytes) + " bytes)");
+    return PGT_OK;
+}
+
 // RAII device buffer for the host-buffer entry points
 struct DevBuf {
     void *p = nullptr;
@@ -228,7 +236,7 @@ int pgt_last_kernel_ms(pgt_ctx *ctx, float *build_ms, float *query_ms) {
 
 int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *a, const double *const *b,
                              uint32_t n_pairs, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out,
-                             void *tree, size_t tree_bytes, void *stream) {
+                             size_t out_bytes, void *tree, size_t tree_bytes, void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0) return PGT_OK;  // a shard without windows (more ranks than windows)
     if (!a || !b || n_pairs == 0 || !tree || (n_win && (!win || !out || !pos)))
@@ -238,19 +246,21 @@ int pgt_fst_reduce_pairs_dev(pgt_ctx *ctx, const uint32_t *pos, const double *co
             return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: f64 columns must be non-NULL and 16-byte aligned");
     if (!aligned16(tree) || tree_bytes < (size_t)n_pairs * pgt_tree_bytes(PGT_STAT_FST, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: tree workspace too small or misaligned");
+    if (n_win > UINT64_MAX / n_pairs) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: n_pairs * n_win overflows");
+    if (int rc = room_check(ctx, "pgt_fst_reduce", (uint64_t)n_pairs * n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_fst(pos, a, b, n_pairs, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
 }
 
 int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
-                       const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, size_t tree_bytes,
-                       void *stream) {
+                       const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes, void *tree,
+                       size_t tree_bytes, void *stream) {
     const double *pa[1] = {a}, *pb[1] = {b};
-    return pgt_fst_reduce_pairs_dev(ctx, pos, pa, pb, 1, n, win, n_win, out, tree, tree_bytes, stream);
+    return pgt_fst_reduce_pairs_dev(ctx, pos, pa, pb, 1, n, win, n_win, out, out_bytes, tree, tree_bytes, stream);
 }
 
 int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
-                       uint64_t n_win, pgt_het_row *out, void *tree, size_t tree_bytes, void *stream) {
+                       uint64_t n_win, pgt_het_row *out, size_t out_bytes, void *tree, size_t tree_bytes, void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0) return PGT_OK;
     if (!g || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
@@ -258,13 +268,14 @@ int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: at most 2^32-1 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_HET, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: tree workspace too small or misaligned");
+    if (int rc = room_check(ctx, "pgt_het_reduce", n_win, sizeof(pgt_het_row), out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_het(pos, g, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
 }
 
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                        const int32_t *n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
-                       pgt_dxy_row *out, pgt_dxy_total *tot, void *tree, size_t tree_bytes, void *stream) {
+                       pgt_dxy_row *out, size_t out_bytes, pgt_dxy_total *tot, void *tree, size_t tree_bytes, void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0 && !tot) return PGT_OK;
     if (!p1 || !p2 || !n1 || !n2 || !tree || (n_win && (!win || !out)))
@@ -274,6 +285,7 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: at most 2^32-1 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: tree workspace too small or misaligned");
+    if (int rc = room_check(ctx, "pgt_dxy_reduce", n_win, sizeof(pgt_dxy_row), out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_dxy(pos, p1, p2, n1, n2, n, minind, win, n_win, out, tot, tree, stream, e.b0, e.b1, e.q1,
                       &ctx->error, ctx->hints);
@@ -281,8 +293,9 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
 
 int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
                            const int32_t *n2, const int8_t *g1, const int8_t *g2, uint64_t n, int minind,
-                           const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, pgt_dxy_total *tot,
-                           pgt_het_row *het_out1, pgt_het_row *het_out2, void *tree, size_t tree_bytes, void *stream) {
+                           const pgt_win *win, uint64_t n_win, pgt_dxy_row *dxy_out, size_t dxy_out_bytes, pgt_dxy_total *tot,
+                           pgt_het_row *het_out1, pgt_het_row *het_out2, size_t het_out_bytes, void *tree, size_t tree_bytes,
+                           void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0 && !tot) return PGT_OK;
     if (!p1 || !p2 || !n1 || !n2 || !g1 || !g2 || !tree || (n_win && (!win || !dxy_out || !het_out1 || !het_out2 || !pos)))
@@ -293,6 +306,8 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: at most 2^32-1 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n) + 2 * pgt_tree_bytes(PGT_STAT_HET, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: tree workspace too small or misaligned");
+    if (int rc = room_check(ctx, "pgt_dxy_het_reduce (dxy rows)", n_win, sizeof(pgt_dxy_row), dxy_out_bytes)) return rc;
+    if (int rc = room_check(ctx, "pgt_dxy_het_reduce (het rows)", n_win, sizeof(pgt_het_row), het_out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_dxy_het(pos, p1, p2, n1, n2, g1, g2, n, minind, win, n_win, dxy_out, tot, het_out1, het_out2, tree,
                           stream, e.b0, e.b1, e.q1, &ctx->error, ctx->hints);
@@ -304,8 +319,8 @@ size_t pgt_af_tree_bytes(uint32_t n_pops, uint64_t n_sites) {
 }
 
 int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const *freq, const double *nsamp,
-                          uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree,
-                          size_t tree_bytes, void *stream) {
+                          uint32_t n_pops, uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes,
+                          void *tree, size_t tree_bytes, void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0) return PGT_OK;
     if (!freq || !nsamp || !tree || (n_win && (!win || !out || !pos)))
@@ -318,14 +333,16 @@ int pgt_fst_af_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *const
     }
     if (!aligned16(tree) || tree_bytes < pgt_af_tree_bytes(n_pops, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: tree workspace too small or misaligned");
+    if (n_win > UINT64_MAX / 28) return ctx_fail(ctx, PGT_EARG, "pgt_fst_af_reduce: n_pairs * n_win overflows");
+    if (int rc = room_check(ctx, "pgt_fst_af_reduce", (uint64_t)(n_pops * (n_pops - 1) / 2) * n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_fst_af(pos, freq, nsamp, n_pops, n, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
                          ctx->hints);
 }
 
 int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
-                           const pgt_win *win, uint64_t n_win, pgt_ext_row *out, void *tree, size_t tree_bytes,
-                           void *stream) {
+                           const pgt_win *win, uint64_t n_win, pgt_ext_row *out, size_t out_bytes, void *tree,
+                           size_t tree_bytes, void *stream) {
     PGT_USE_DEVICE(ctx);
     if (n == 0 && n_win == 0) return PGT_OK;
     if (!score || !tree || (n_win && (!win || !out || !pos))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
@@ -334,6 +351,7 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
     if (n >= 0xFFFFFFFFull) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: at most 2^32-2 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_EXT, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: tree workspace too small or misaligned");
+    if (int rc = room_check(ctx, "pgt_extreme_reduce", n_win, sizeof(pgt_ext_row), out_bytes)) return rc;
     const EvSet e = events_for(ctx);
     return launch_ext(pos, score, n, mode, cutoff, win, n_win, out, tree, stream, e.b0, e.b1, e.q1, &ctx->error,
                       ctx->hints);
@@ -407,6 +425,14 @@ int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t by
     return hip_check(ctx, hipStreamSynchronize(s), "pgt_rowbuf_read: synchronize");
 }
 
+int pgt_rowbuf_fill(pgt_ctx *ctx, void *dev_ptr, size_t bytes, uint64_t seed, void *stream) {
+    PGT_USE_DEVICE(ctx);
+    if (bytes == 0) return PGT_OK;
+    if (!dev_ptr || (bytes & 7u) || (reinterpret_cast<uintptr_t>(dev_ptr) & 7u))
+        return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_fill: NULL or misaligned argument");
+    return launch_fill_pattern(static_cast<uint64_t *>(dev_ptr), bytes / 8, seed, stream, &ctx->error);
+}
+
 /* ---------------- host-buffer entry points ---------------- */
 
 int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
@@ -423,8 +449,8 @@ int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, u
     const size_t tb = pgt_tree_bytes(PGT_STAT_EXT, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
     if (int rc = pgt_extreme_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(ds.p), n, mode, cutoff,
-                                        static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_ext_row *>(dout.p), dtree.p,
-                                        tb, nullptr))
+                                        static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_ext_row *>(dout.p),
+                                        n_win * sizeof(pgt_ext_row), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "extreme kernels")) return rc;
     if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_ext_row), hipMemcpyDeviceToHost), "download rows");
@@ -434,9 +460,10 @@ int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, u
 
 /* device columns (e.g. from pgt_ingest_text), window table and rows in HOST memory */
 int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, const double *d_b, uint64_t n,
-                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
+                        const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_a || !d_b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    if (int rc = room_check(ctx, "pgt_fst_reduce_cols", n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
     DevBuf dwin, dout, dtree;
@@ -445,7 +472,7 @@ int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, 
     const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
     if (int rc = pgt_fst_reduce_dev(ctx, d_pos, d_a, d_b, n, static_cast<pgt_win *>(dwin.p), n_win,
-                                    static_cast<pgt_fst_row *>(dout.p), dtree.p, tb, nullptr))
+                                    static_cast<pgt_fst_row *>(dout.p), n_win * sizeof(pgt_fst_row), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
     if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
@@ -461,13 +488,14 @@ int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const dou
     if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
     if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
     return pgt_fst_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(da.p), static_cast<double *>(db.p), n,
-                               win, n_win, out);
+                               win, n_win, out, n_win * sizeof(pgt_fst_row));
 }
 
 int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, uint64_t n, const pgt_win *win,
-                        uint64_t n_win, pgt_het_row *out) {
+                        uint64_t n_win, pgt_het_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    if (int rc = room_check(ctx, "pgt_het_reduce_cols", n_win, sizeof(pgt_het_row), out_bytes)) return rc;
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
     DevBuf dwin, dout, dtree;
@@ -476,7 +504,7 @@ int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, 
     const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
     if (int rc = pgt_het_reduce_dev(ctx, d_pos, d_g, n, static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_het_row *>(dout.p),
-                                    dtree.p, tb, nullptr))
+                                    n_win * sizeof(pgt_het_row), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
     if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
@@ -490,15 +518,17 @@ int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t 
     DevBuf dpos, dg;
     if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
     if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
-    return pgt_het_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n, win, n_win, out);
+    return pgt_het_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n, win, n_win, out,
+                               n_win * sizeof(pgt_het_row));
 }
 
 int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2, const int32_t *d_n1,
                         const int32_t *d_n2, uint64_t n, int minind, const pgt_win *win, uint64_t n_win,
-                        pgt_dxy_row *out, pgt_dxy_total *tot) {
+                        pgt_dxy_row *out, size_t out_bytes, pgt_dxy_total *tot) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_p1 || !d_p2 || !d_n1 || !d_n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
+    if (int rc = room_check(ctx, "pgt_dxy_reduce_cols", n_win, sizeof(pgt_dxy_row), out_bytes)) return rc;
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
     DevBuf dwin, dout, dtot, dtree;
@@ -508,8 +538,8 @@ int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1,
     const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
     if (int rc = pgt_dxy_reduce_dev(ctx, d_pos, d_p1, d_p2, d_n1, d_n2, n, minind, static_cast<pgt_win *>(dwin.p), n_win,
-                                    static_cast<pgt_dxy_row *>(dout.p), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr,
-                                    dtree.p, tb, nullptr))
+                                    static_cast<pgt_dxy_row *>(dout.p), n_win * sizeof(pgt_dxy_row),
+                                    tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
     if (n_win)
@@ -531,7 +561,8 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
     if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
     if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
     return pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p), static_cast<double *>(d2.p),
-                               static_cast<int32_t *>(dn1.p), static_cast<int32_t *>(dn2.p), n, minind, win, n_win, out, tot);
+                               static_cast<int32_t *>(dn1.p), static_cast<int32_t *>(dn2.p), n, minind, win, n_win, out,
+                               n_win * sizeof(pgt_dxy_row), tot);
 }
 
 /* ---------------- window tables built on the device ---------------- */
@@ -606,9 +637,10 @@ int tab_check(pgt_ctx *ctx, const pgt_wintab *tab, const void *out, const char *
 }  // namespace
 
 int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n, int cols_on_device,
-                       const pgt_wintab *tab, pgt_fst_row *out) {
+                       const pgt_wintab *tab, pgt_fst_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if (int rc = tab_check(ctx, tab, out, "pgt_fst_reduce_tab")) return rc;
+    if (int rc = room_check(ctx, "pgt_fst_reduce_tab", tab->n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
     if (n && (!pos || !a || !b)) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce_tab: NULL argument");
     if (tab->n_win == 0) return PGT_OK;
     DevBuf dpos, da, db, dout, dtree;
@@ -622,16 +654,18 @@ int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const
     if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
     const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_fst_reduce_dev(ctx, pos, a, b, n, tab->d_win, tab->n_win, static_cast<pgt_fst_row *>(dout.p), dtree.p, tb, nullptr))
+    if (int rc = pgt_fst_reduce_dev(ctx, pos, a, b, n, tab->d_win, tab->n_win, static_cast<pgt_fst_row *>(dout.p),
+                                    tab->n_win * sizeof(pgt_fst_row), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
     return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
 }
 
 int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, int cols_on_device, const pgt_wintab *tab,
-                       pgt_het_row *out) {
+                       pgt_het_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if (int rc = tab_check(ctx, tab, out, "pgt_het_reduce_tab")) return rc;
+    if (int rc = room_check(ctx, "pgt_het_reduce_tab", tab->n_win, sizeof(pgt_het_row), out_bytes)) return rc;
     if (n && (!pos || !g)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce_tab: NULL argument");
     if (tab->n_win == 0) return PGT_OK;
     DevBuf dpos, dg, dout, dtree;
@@ -644,15 +678,19 @@ int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
     if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
     const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_het_reduce_dev(ctx, pos, g, n, tab->d_win, tab->n_win, static_cast<pgt_het_row *>(dout.p), dtree.p, tb, nullptr)) return rc;
+    if (int rc = pgt_het_reduce_dev(ctx, pos, g, n, tab->d_win, tab->n_win, static_cast<pgt_het_row *>(dout.p),
+                                    tab->n_win * sizeof(pgt_het_row), dtree.p, tb, nullptr))
+        return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
     return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
 }
 
 int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
-                       uint64_t n, int minind, int cols_on_device, const pgt_wintab *tab, pgt_dxy_row *out, pgt_dxy_total *tot) {
+                       uint64_t n, int minind, int cols_on_device, const pgt_wintab *tab, pgt_dxy_row *out, size_t out_bytes,
+                       pgt_dxy_total *tot) {
     PGT_USE_DEVICE(ctx);
     if (int rc = tab_check(ctx, tab, out, "pgt_dxy_reduce_tab")) return rc;
+    if (int rc = room_check(ctx, "pgt_dxy_reduce_tab", tab->n_win, sizeof(pgt_dxy_row), out_bytes)) return rc;
     if (n && (!pos || !p1 || !p2 || !n1 || !n2)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce_tab: NULL argument");
     DevBuf dpos, d1, d2, dn1, dn2, dout, dtot, dtree;
     if (!cols_on_device) {
@@ -670,7 +708,8 @@ int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
     const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
     if (int rc = pgt_dxy_reduce_dev(ctx, pos, p1, p2, n1, n2, n, minind, tab->d_win, tab->n_win, static_cast<pgt_dxy_row *>(dout.p),
-                                    tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb, nullptr))
+                                    tab->n_win * sizeof(pgt_dxy_row), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb,
+                                    nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
     if (tab->n_win)

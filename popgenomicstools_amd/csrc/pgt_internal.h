@@ -170,6 +170,9 @@ int plan_site_windows(const uint64_t *run_len, size_t n_runs, uint32_t W, uint32
 int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_win, uint32_t W, uint32_t S, pgt_win *d_out,
                              void *stream, std::string *err);
 
+// pgt_kernels.hip: words[i] = splitmix64(seed + i) by plain global stores (pgt_rowbuf_fill: mapping self-test)
+int launch_fill_pattern(uint64_t *words, uint64_t n_words, uint64_t seed, void *stream, std::string *err);
+
 // pgt_ingest.hip: text -> device columns + chromosome runs (synchronous, default stream of `device`)
 int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err);
 size_t ingest_column_bytes(const pgt_ingest *ing, int token);  // rows * element size of the token's column (0: no column)

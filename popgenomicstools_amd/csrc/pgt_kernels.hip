@@ -1122,7 +1122,26 @@ __global__ __launch_bounds__(256) void windows_from_plan_kernel(const RunPlan *_
     }
 }
 
+// pgt_rowbuf_fill: the pattern a rank stores through a freshly mapped peer buffer before the mapping is trusted
+__global__ __launch_bounds__(256) void fill_pattern_kernel(uint64_t *__restrict__ words, uint64_t n_words, uint64_t seed) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+        uint64_t z = seed + i + 0x9E3779B97F4A7C15ull;  // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        words[i] = z ^ (z >> 31);
+    }
+}
+
 }  // namespace
+
+int launch_fill_pattern(uint64_t *words, uint64_t n_words, uint64_t seed, void *stream, std::string *err) {
+    if (n_words == 0) return PGT_OK;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), words, n_words, seed);
+    return hip_fail(hipGetLastError(), "fill_pattern_kernel", err);
+}
 
 int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_win, uint32_t W, uint32_t S, pgt_win *d_out,
                              void *stream, std::string *err) {

@@ -14,8 +14,13 @@ Two transports (RowExchange):
   gather  torch.distributed.gather of the rows (backend "nccl" = RCCL over xGMI; gloo in the CPU
           tests), asynchronous and double-buffered so that the gather of scan k overlaps scan k+1.
 
-`mode="auto"` takes peer when every rank could map the buffer and falls back to gather otherwise
-(decided collectively, so all ranks agree).
+`mode="gather"` is the default and what `mode="auto"` means: peer stores have been rehearsed (several
+processes on ONE GPU) but the gpurun boxes have a single GPU, so until a run on real xGMI has proven
+them they are opt-in.  `mode="peer"` raises when some rank cannot map the buffer; `mode="peer_or_gather"`
+falls back to the gather instead (decided collectively, so all ranks agree).  A freshly mapped buffer is
+never trusted blindly: every rank first stores a test pattern through its slice with a kernel
+(pgt_rowbuf_fill: the same plain global stores the query kernels use), `dst` reads the whole buffer back
+and compares; a mismatch counts as "cannot map".
 """
 from __future__ import annotations
 
@@ -48,7 +53,7 @@ class RowGatherer:
     """gather_rows with its buffers allocated once (the per-scan path): when every rank has the same
     number of rows the local row tensor is sent as it is, no staging copy.  `dst` is a rank of `group`."""
 
-    def __init__(self, counts, row_bytes: int, device, dst: int = 0, group=None):
+    def __init__(self, counts, row_bytes: int, device, dst: int = 0, group=None, slots: int = 1):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -60,8 +65,10 @@ class RowGatherer:
         self.width = max(max(self.counts) * row_bytes, 1)
         self.uniform = len(set(self.counts)) == 1 and self.counts[0] > 0
         self.send = None if self.uniform else torch.zeros(self.width, dtype=torch.uint8, device=device)
-        self.recv = ([torch.empty(self.width, dtype=torch.uint8, device=device) for _ in range(self.world)]
-                     if self.rank == dst else None)
+        # one receive set PER SLOT: two gathers in flight (RowExchange) never write the same tensors, so the
+        # order in which a backend completes them (gloo: worker threads) cannot mix two scans' rows
+        self.recvs = ([[torch.empty(self.width, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                       for _ in range(max(1, slots))] if self.rank == dst else None)
 
     def _staged(self, local_rows):
         if self.uniform:
@@ -75,24 +82,27 @@ class RowGatherer:
         `local_rows` untouched until handle.wait() (a stream-level wait) has been issued, and — when the
         counts differ between ranks, i.e. when the rows go through the one staging buffer — must not
         call start() again before that wait.  RowExchange avoids the staging copy with start_padded()."""
-        return self.dist.gather(self._staged(local_rows), self.recv, dst=self.gdst, group=self.group, async_op=True)
+        return self.dist.gather(self._staged(local_rows), self._recv(0), dst=self.gdst, group=self.group, async_op=True)
 
-    def start_padded(self, padded_rows):
+    def _recv(self, slot):
+        return self.recvs[slot] if self.recvs is not None else None
+
+    def start_padded(self, padded_rows, slot: int = 0):
         """Asynchronous gather of a caller-owned buffer of exactly `width` bytes (its first counts[rank] *
-        row_bytes bytes are the rows): no staging copy, so several gathers may be in flight as long as
-        each has its own buffer."""
+        row_bytes bytes are the rows) into receive set `slot`: no staging copy, so several gathers may be
+        in flight as long as each has its own send buffer and its own slot."""
         assert padded_rows.numel() == self.width
-        return self.dist.gather(padded_rows, self.recv, dst=self.gdst, group=self.group, async_op=True)
+        return self.dist.gather(padded_rows, self._recv(slot), dst=self.gdst, group=self.group, async_op=True)
 
     def __call__(self, local_rows):
         """Returns on dst the list of per-rank row tensors (views, valid until the next call)."""
-        self.dist.gather(self._staged(local_rows), self.recv, dst=self.gdst, group=self.group)
+        self.dist.gather(self._staged(local_rows), self._recv(0), dst=self.gdst, group=self.group)
         return self.parts()
 
-    def parts(self):
+    def parts(self, slot: int = 0):
         if self.rank != self.dst:
             return None
-        return [self.recv[r][: self.counts[r] * self.row_bytes] for r in range(self.world)]
+        return [self.recvs[slot][r][: self.counts[r] * self.row_bytes] for r in range(self.world)]
 
 
 def gather_rows(local_rows, counts, row_bytes: int, dst: int = 0, group=None):
@@ -127,7 +137,7 @@ class RowExchange:
     CPU for gloo); defaults to `device`.
     """
 
-    def __init__(self, ctx, counts, row_bytes: int, device, dst: int = 0, group=None, mode: str = "auto",
+    def __init__(self, ctx, counts, row_bytes: int, device, dst: int = 0, group=None, mode: str = "gather",
                  tables: int = 1, coll_device=None):
         import torch
         import torch.distributed as dist
@@ -143,17 +153,19 @@ class RowExchange:
         for r in range(1, self.world):
             self.offsets[r] = _align(self.offsets[r - 1] + self.counts[r - 1] * self.row_bytes)
         self.total = _align(self.offsets[-1] + self.counts[-1] * self.row_bytes)
-        self.mode = "local" if self.world == 1 else mode
+        if mode not in ("auto", "gather", "peer", "peer_or_gather", "local"):
+            raise PgtError(1, f"RowExchange: unknown mode {mode!r}")
+        self.mode = "local" if self.world == 1 else ("gather" if mode == "auto" else mode)
         self.buf = None       # peer: the shared row buffer (owned on dst, mapped elsewhere)
         self.peer_error = ""
-        if self.mode in ("auto", "peer"):
+        if self.mode in ("peer_or_gather", "peer"):
             ok = self._setup_peer()
             if not ok and self.mode == "peer":
                 raise PgtError(3, "RowExchange: peer mapping of the row buffer failed on some rank: " + self.peer_error)
             self.mode = "peer" if ok else "gather"
         if self.mode in ("gather", "local"):
             depth = 2 if self.mode == "gather" else 1
-            self.gatherer = (RowGatherer(self.counts, self.row_bytes, self.coll_device, dst=dst, group=group)
+            self.gatherer = (RowGatherer(self.counts, self.row_bytes, self.coll_device, dst=dst, group=group, slots=depth)
                              if self.mode == "gather" else None)
             # each slot is a full-width send buffer whose head is this rank's rows: the kernel writes the rows
             # where the gather reads them, no staging copy, two gathers in flight never share a buffer
@@ -161,6 +173,7 @@ class RowExchange:
             self.bufs = [torch.zeros(width, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.outs = [b[: self.my_bytes] for b in self.bufs]
             self.pending = [None] * depth
+            self.staged = [None] * depth  # rehearsal over gloo: the CPU copy a gather reads, one per slot
             self.k = 0
             self.last = 0
 
@@ -193,11 +206,36 @@ class RowExchange:
                     self.peer_error, ok = str(e), 0
         flag = torch.tensor([ok], dtype=torch.int32, device=self.coll_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 1:
+        if int(flag.item()) == 1 and self._peer_selftest():
             self.my_out = self.buf.view(self.offsets[self.rank], self.my_bytes)
             return True
         self._close_peer()
         return False
+
+    def _peer_selftest(self) -> bool:
+        """Every rank stores a pattern through its slice of the mapped buffer with a kernel, dst reads the whole
+        buffer back and compares.  Collective; all ranks get the same answer."""
+        dist, torch = self.dist, self.torch
+        ok = 1
+        try:
+            if self.my_bytes >= 8:
+                self.ctx.rowbuf_fill(self.buf.view(self.offsets[self.rank], self.my_bytes // 8 * 8), seed=1000 + self.rank)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+        except PgtError as e:
+            self.peer_error, ok = "self-test store: " + str(e), 0
+        dist.barrier(group=self.group)  # every rank's stores have completed on its side
+        if self.rank == self.dst and ok:
+            raw = self.ctx.rowbuf_read(self.buf, self.total)
+            for r in range(self.world):
+                nw = self.counts[r] * self.row_bytes // 8
+                got = raw[self.offsets[r]: self.offsets[r] + 8 * nw].view(np.uint64)
+                if not np.array_equal(got, self.ctx.pattern_words(nw, 1000 + r)):
+                    self.peer_error, ok = f"self-test: the pattern rank {r} stored did not arrive in rank {self.dst}'s buffer", 0
+                    break
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
 
     def _close_peer(self):
         if self.buf is not None:
@@ -221,8 +259,8 @@ class RowExchange:
             rows = self.bufs[self.k]
             if self.coll_device != self.device and self.coll_device.type == "cpu":
                 rows = rows.cpu()  # rehearsal over gloo: CPU staging (synchronises)
-            self._host_rows = rows  # keep a staged CPU copy alive until the gather has read it
-            self.pending[self.k] = self.gatherer.start_padded(rows)
+            self.staged[self.k] = rows  # keep a staged CPU copy alive until its gather has read it (one per slot)
+            self.pending[self.k] = self.gatherer.start_padded(rows, slot=self.k)
             self.last = self.k
             self.k ^= 1
         elif self.mode == "local":
@@ -250,7 +288,7 @@ class RowExchange:
             raw = self.ctx.rowbuf_read(self.buf, self.total)
             parts = [raw[self.offsets[r]: self.offsets[r] + self.counts[r] * self.row_bytes] for r in range(self.world)]
         elif self.mode == "gather":
-            parts = [p.cpu().numpy() for p in self.gatherer.parts()]
+            parts = [p.cpu().numpy() for p in self.gatherer.parts(self.last)]
         else:
             parts = [self.outs[0].cpu().numpy()]
         if self.tables == 1:
@@ -276,8 +314,12 @@ def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows
                     (table-major) into `out`, e.g. lambda c, w, out: ctx.fst_reduce_dev(*c, windows_to_device(w, dev), out=out)
       tables        rows per window: 1, or the number of population pairs of fst_reduce_pairs_dev /
                     fst_af_reduce_dev (BASELINE config 5)
-      mode          "gather" (one RCCL/gloo gather) or "peer"/"auto" (needs ctx: rows stored straight into
-                    dst's buffer over xGMI)
+      mode          "gather" (one RCCL/gloo gather; = "auto") or "peer" / "peer_or_gather" (needs ctx: rows stored
+                    straight into dst's buffer over xGMI after a self-test of the mapping)
+      ctx           when given, its hints (longest window, typical step) are set from the WHOLE table for the
+                    duration of the call, so that every rank — and a single-GPU run that does the same — picks the
+                    same query strategy and tree levels: rows are bitwise independent of the number of ranks only
+                    under identical hints (the strategies sum in different orders)
     Returns on `dst` (a rank of `group`) the assembled rows as a numpy structured array, table-major over
     all windows; None elsewhere.  A rank whose shard holds no window (more ranks than windows) loads
     nothing, reduces nothing and still takes part in the exchange.
@@ -293,13 +335,29 @@ def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows
     out = ex.begin()
     if local_win.size:
         columns = load_columns(int(shard["site_lo"]), int(shard["site_hi"]))
-        reduce_rows(columns, local_win, out)
+        if ctx is not None:
+            with ctx.hints(*table_hints(win)):
+                reduce_rows(columns, local_win, out)
+        else:
+            reduce_rows(columns, local_win, out)
     ex.end()
     packed = ex.finish()
     ex.close()
     if rank != dst:
         return None
     return np.frombuffer(packed.tobytes(), dtype=row_dtype)
+
+
+def table_hints(win: np.ndarray):
+    """(longest window, typical step) of a whole window table: what pgt_set_max_window / pgt_set_window_step
+    should be given on every rank that reduces a slice of it (the median start distance, as the host-buffer
+    entry points derive it)."""
+    if win.size == 0:
+        return 0, 0
+    span = win["hi"].astype(np.int64) - win["lo"].astype(np.int64)
+    d = np.diff(win["lo"].astype(np.int64))
+    d = d[d >= 0]
+    return int(max(span.max(), 1)), (int(np.median(d)) if d.size else 0)
 
 
 TOTAL_BLOCK = 1 << 16  # sites per block of the genome-wide dxy total (= the smallest shard alignment)
@@ -358,7 +416,9 @@ def sharded_dxy_scan(win: np.ndarray, n_sites: int, load_columns, ctx, minind: i
     out = ex.begin()
     if counts[rank]:
         pos, p1, p2, n1, n2 = load_columns(lo, hi)
-        ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, minind, windows_to_device(local, device), out=out)
+        with ctx.hints(*table_hints(win)):  # strategy and levels follow the whole table, not this rank's slice
+            # tot=False: the genome-wide line comes from the 2^16-site block rows below, not from a whole-shard query
+            ctx.dxy_reduce_dev(pos, p1, p2, n1, n2, minind, windows_to_device(local, device), out=out, tot=False)
     ex.end()
     packed = ex.finish()
     ex.close()

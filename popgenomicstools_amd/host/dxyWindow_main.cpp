@@ -282,9 +282,9 @@ int main(int argc, char **argv) {
         n1 = m1.dev.col<int32_t>(6); n2 = m2.dev.col<int32_t>(6);
     }
     if (sw.tab)
-        check(pgt_dxy_reduce_tab(ctx, pos, p1, p2, n1, n2, n_sites, minind, on_device, sw.tab, rows.data(), &tot), ctx);
+        check(pgt_dxy_reduce_tab(ctx, pos, p1, p2, n1, n2, n_sites, minind, on_device, sw.tab, rows.data(), rows.size() * sizeof(rows[0]), &tot), ctx);
     else if (on_device)
-        check(pgt_dxy_reduce_cols(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
+        check(pgt_dxy_reduce_cols(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), rows.size() * sizeof(rows[0]), &tot), ctx);
     else
         check(pgt_dxy_reduce(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), &tot), ctx);
     timer.lap("gpu reduce");

@@ -89,9 +89,9 @@ int main(int argc, char **argv) {
     const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
     const double *a = on_device ? dtab.col<double>(2) : tab.a.data(), *b = on_device ? dtab.col<double>(3) : tab.b.data();
     if (sw.tab)
-        check(pgt_fst_reduce_tab(ctx, pos, a, b, n, on_device, sw.tab, rows.data()), ctx);
+        check(pgt_fst_reduce_tab(ctx, pos, a, b, n, on_device, sw.tab, rows.data(), rows.size() * sizeof(rows[0])), ctx);
     else if (on_device)
-        check(pgt_fst_reduce_cols(ctx, pos, a, b, n, sw.win.data(), n_win, rows.data()), ctx);
+        check(pgt_fst_reduce_cols(ctx, pos, a, b, n, sw.win.data(), n_win, rows.data(), rows.size() * sizeof(rows[0])), ctx);
     else
         check(pgt_fst_reduce(ctx, pos, a, b, n, sw.win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");

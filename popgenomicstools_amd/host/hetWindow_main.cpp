@@ -93,9 +93,9 @@ int main(int argc, char **argv) {
     const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
     const int8_t *g = on_device ? dtab.col<int8_t>(2) : tab.g.data();
     if (sw.tab)
-        check(pgt_het_reduce_tab(ctx, pos, g, n, on_device, sw.tab, rows.data()), ctx);
+        check(pgt_het_reduce_tab(ctx, pos, g, n, on_device, sw.tab, rows.data(), rows.size() * sizeof(rows[0])), ctx);
     else if (on_device)
-        check(pgt_het_reduce_cols(ctx, pos, g, n, sw.win.data(), n_win, rows.data()), ctx);
+        check(pgt_het_reduce_cols(ctx, pos, g, n, sw.win.data(), n_win, rows.data(), rows.size() * sizeof(rows[0])), ctx);
     else
         check(pgt_het_reduce(ctx, pos, g, n, sw.win.data(), n_win, rows.data()), ctx);
     timer.lap("gpu reduce");

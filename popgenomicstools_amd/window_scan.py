@@ -319,7 +319,7 @@ class Context:
 
     @staticmethod
     def _room(name, buf, need_bytes):
-        """The C ABI gets no output capacity: an undersized buffer would be a silent device overrun."""
+        """Early, readable refusal; the C ABI (version 4) checks the same capacities again before any launch."""
         if buf.numel() < need_bytes:
             raise PgtError(_lib.PGT_EARG, f"{name}: buffer holds {buf.numel()} bytes, {need_bytes} needed")
 
@@ -350,7 +350,7 @@ class Context:
             raise PgtError(_lib.PGT_EARG, "fst_reduce_tab: column lengths differ")
         out = np.zeros(tab.n_win, dtype=FST_ROW_DTYPE)
         self._check(self._lib.pgt_fst_reduce_tab(self._ctx, pos.ctypes.data, a.ctypes.data, b.ctypes.data, pos.size, 0, tab._h,
-                                                 out.ctypes.data))
+                                                 out.ctypes.data, out.nbytes))
         return out
 
     def het_reduce_tab(self, pos, g, tab: WindowTable) -> np.ndarray:
@@ -359,7 +359,8 @@ class Context:
         if pos.size != g.size:
             raise PgtError(_lib.PGT_EARG, "het_reduce_tab: column lengths differ")
         out = np.zeros(tab.n_win, dtype=HET_ROW_DTYPE)
-        self._check(self._lib.pgt_het_reduce_tab(self._ctx, pos.ctypes.data, g.ctypes.data, pos.size, 0, tab._h, out.ctypes.data))
+        self._check(self._lib.pgt_het_reduce_tab(self._ctx, pos.ctypes.data, g.ctypes.data, pos.size, 0, tab._h, out.ctypes.data,
+                                                 out.nbytes))
         return out
 
     def dxy_reduce_tab(self, pos, p1, p2, n1, n2, minind, tab: WindowTable):
@@ -373,7 +374,8 @@ class Context:
         out = np.zeros(tab.n_win, dtype=DXY_ROW_DTYPE)
         tot = np.zeros(1, dtype=DXY_TOTAL_DTYPE)
         self._check(self._lib.pgt_dxy_reduce_tab(self._ctx, pos.ctypes.data, p1.ctypes.data, p2.ctypes.data, n1.ctypes.data,
-                                                 n2.ctypes.data, pos.size, int(minind), 0, tab._h, out.ctypes.data, tot.ctypes.data))
+                                                 n2.ctypes.data, pos.size, int(minind), 0, tab._h, out.ctypes.data, out.nbytes,
+                                                 tot.ctypes.data))
         return out, tot[0]
 
     # ---- multi-GPU row buffer (pgt_rowbuf_*) ------------------------------------------------
@@ -396,6 +398,20 @@ class Context:
 
     def rowbuf_close(self, buf: RowBuffer, owner: bool):
         self._check(self._lib.pgt_rowbuf_close(self._ctx, C.c_void_p(buf.data_ptr()), int(owner)))
+
+    def rowbuf_fill(self, buf: RowBuffer, seed: int, stream=None):
+        """Store the test pattern of pgt_rowbuf_fill through `buf` (asynchronous); pattern_words() is what must read back."""
+        self._check(self._lib.pgt_rowbuf_fill(self._ctx, C.c_void_p(buf.data_ptr()), buf.numel() // 8 * 8, int(seed),
+                                              self._stream(stream)))
+
+    @staticmethod
+    def pattern_words(n_words: int, seed: int) -> np.ndarray:
+        """The words pgt_rowbuf_fill writes: splitmix64(seed + i)."""
+        with np.errstate(over="ignore"):
+            z = np.arange(n_words, dtype=np.uint64) + np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return z ^ (z >> np.uint64(31))
 
     def rowbuf_read(self, buf: RowBuffer, nbytes: int | None = None, stream=None) -> np.ndarray:
         nbytes = buf.numel() if nbytes is None else int(nbytes)
@@ -421,7 +437,7 @@ class Context:
         self._check(self._lib.pgt_fst_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(a, torch.float64, "a"),
             self._dev(b, torch.float64, "b"), n, self._dev(win, torch.uint8, "win"), n_win,
-            self._dev(out, torch.uint8, "out"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
+            self._dev(out, torch.uint8, "out"), out.numel(), self._dev(tree, torch.uint8, "tree"), tree.numel(),
             self._stream(stream)))
         return out, tree
 
@@ -442,7 +458,7 @@ class Context:
         pb = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "b") for t in b_list])
         self._check(self._lib.pgt_fst_reduce_pairs_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), pa, pb, n_pairs, n,
-            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree
 
@@ -459,11 +475,13 @@ class Context:
         self._room("het_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_HET, n))
         self._check(self._lib.pgt_het_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(g, torch.int8, "g"), n,
-            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree
 
     def dxy_reduce_dev(self, pos, p1, p2, n1, n2, minind, win, out=None, tot=None, tree=None, stream=None):
+        """tot: None = a fresh total buffer is allocated and filled; False = no genome-wide total is wanted (the C
+        ABI's tot == NULL: only the tree levels the windows need are built, no whole-input query runs)."""
         import torch
         n = p1.numel()
         n_win = win.numel() // WIN_DTYPE.itemsize
@@ -473,6 +491,8 @@ class Context:
             out = torch.empty(n_win * DXY_ROW_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
         if tot is None:
             tot = torch.empty(DXY_TOTAL_DTYPE.itemsize, dtype=torch.uint8, device=p1.device)
+        elif tot is False:
+            tot = None
         self._same_len("dxy_reduce_dev", n, pos, p1, p2, n1, n2)
         self._room("dxy_reduce_dev: out", out, n_win * DXY_ROW_DTYPE.itemsize)
         self._room("dxy_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_DXY, n))
@@ -480,7 +500,8 @@ class Context:
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
             self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
             n, int(minind), self._dev(win, torch.uint8, "win") if n_win else None, n_win,
-            self._dev(out, torch.uint8, "out") if n_win else None, self._dev(tot, torch.uint8, "tot"),
+            self._dev(out, torch.uint8, "out") if n_win else None, out.numel(),
+            self._dev(tot, torch.uint8, "tot") if tot is not None else None,
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tot, tree
 
@@ -503,10 +524,10 @@ class Context:
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
             self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
             self._dev(g1, torch.int8, "g1"), self._dev(g2, torch.int8, "g2"), n, int(minind),
-            self._dev(win, torch.uint8, "win"), n_win, self._dev(dxy_out, torch.uint8, "dxy_out"),
+            self._dev(win, torch.uint8, "win"), n_win, self._dev(dxy_out, torch.uint8, "dxy_out"), dxy_out.numel(),
             self._dev(tot, torch.uint8, "tot"), self._dev(h1, torch.uint8, "het_out1"),
-            self._dev(h2, torch.uint8, "het_out2"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
-            self._stream(stream)))
+            self._dev(h2, torch.uint8, "het_out2"), min(h1.numel(), h2.numel()), self._dev(tree, torch.uint8, "tree"),
+            tree.numel(), self._stream(stream)))
         return dxy_out, tot, h1, h2, tree
 
     def fst_af_reduce_dev(self, pos, freqs, nsamp, win, out=None, tree=None, stream=None):
@@ -529,7 +550,7 @@ class Context:
         ns = (C.c_double * n_pops)(*[float(x) for x in nsamp])
         self._check(self._lib.pgt_fst_af_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), pf, ns, n_pops, n, self._dev(win, torch.uint8, "win"),
-            n_win, self._dev(out, torch.uint8, "out"), self._dev(tree, torch.uint8, "tree"), tree.numel(),
+            n_win, self._dev(out, torch.uint8, "out"), out.numel(), self._dev(tree, torch.uint8, "tree"), tree.numel(),
             self._stream(stream)))
         return out, tree
 
@@ -548,18 +569,36 @@ class Context:
         self._room("extreme_reduce_dev: tree", tree, tb)
         self._check(self._lib.pgt_extreme_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(score, torch.float64, "score"), n, int(mode),
-            float(cutoff), self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"),
+            float(cutoff), self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree
 
     def set_max_window(self, sites: int):
         """Performance hint for the *_dev calls: no window is longer than `sites` (0 = unknown)."""
         self._check(self._lib.pgt_set_max_window(self._ctx, int(sites)))
+        self._hints = (int(sites), getattr(self, "_hints", (0, 0))[1])
 
     def set_window_step(self, sites: int):
         """Performance hint for the *_dev calls: consecutive windows start `sites` apart (0 = unknown);
-        steps of at most 32 sites select the sliding query (include/pgtwin.h)."""
+        small steps select the sliding query (include/pgtwin.h)."""
         self._check(self._lib.pgt_set_window_step(self._ctx, int(sites)))
+        self._hints = (getattr(self, "_hints", (0, 0))[0], int(sites))
+
+    def hints(self, max_window: int, window_step: int):
+        """with ctx.hints(max_window, step): ... — both hints for the duration of the block, then the previous ones."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            saved = getattr(self, "_hints", (0, 0))
+            self.set_max_window(max_window)
+            self.set_window_step(window_step)
+            try:
+                yield self
+            finally:
+                self.set_max_window(saved[0])
+                self.set_window_step(saved[1])
+        return scope()
 
     # ---- per-kernel timing ------------------------------------------------------------------
     def set_profiling(self, enabled: bool):

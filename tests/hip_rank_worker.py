@@ -45,7 +45,7 @@ def main():
         ctx.fst_reduce_dev(*c, windows_to_device(w, dev), out=out)
     ref = whole(lambda: rows_from_device(ctx.fst_reduce_dev(*g.fst_columns_t(0, n, dev), windows_to_device(win, dev))[0],
                                          FST_ROW_DTYPE).tobytes())
-    for mode in ("gather", "peer", "auto"):
+    for mode in ("gather", "peer", "peer_or_gather", "auto"):
         got = sharded_scan(win, FST_ROW_DTYPE, lambda lo, hi: g.fst_columns_t(lo, hi, dev), fst_reduce, dev,
                            ctx=ctx, mode=mode, coll_device=cpu)
         if rank == 0:

@@ -36,3 +36,29 @@ def test_bench_single_and_two_rank_tables_agree(workload):
         assert two["rows_check"].startswith("bitwise equal")
         assert two["rows_sha256"] == one["rows_sha256"]
         assert sum(two["config"]["sites_resident_per_gpu"]) < 1.2 * one["config"]["sites_total"]
+        assert two["extra"]["exchange_" + mode]["rows_check"] == "bitwise equal" and two["extra"]["exchange_" + mode]["headline"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver calls it for N = 1 (no launcher, no WORLD_SIZE): the parent starts
+    the two ranks as a child process group, relays rank 0's line and exits with the child's code.  Default --exchange
+    auto: BOTH transports are timed, each table is checked bit for bit, the headline is one of the verified ones."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PGT_BENCH_BACKEND="gloo", PGT_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
+                               env=env, timeout=400))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env,
+                       timeout=500)
+    two = _line(r)
+    assert two["n_gpus"] == 2 and two["rows_check"].startswith("bitwise equal") and two["rows_sha256"] == one["rows_sha256"]
+    ex = two["extra"]
+    assert ex["exchange_gather"]["rows_check"] == "bitwise equal" and ex["exchange_gather"]["ms_per_step"] > 0
+    assert ex["exchange_peer"]["rows_check"] == "bitwise equal" and ex["exchange_peer"]["ms_per_step"] > 0
+    assert [ex[k]["headline"] for k in ("exchange_gather", "exchange_peer")].count(True) == 1
+    assert two["config"]["row_exchange"] in ("gather", "peer")
+    # a failing rank is a failing bench: the parent passes the child's exit code on
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stepsize", "0"] + SMALL, capture_output=True,
+                         text=True, env=env, timeout=300)
+    assert bad.returncode != 0

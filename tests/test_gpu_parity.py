@@ -619,12 +619,53 @@ def test_device_api_argument_checks(pgt, ctx):
     g = torch.zeros(1024, dtype=torch.int8, device=dev)
     tree = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
     out = torch.empty(win.numel() // 32 * 32, dtype=torch.uint8, device=dev)
-    rc = lib.pgt_het_reduce_dev(ctx._ctx, pos.data_ptr(), g.data_ptr(), 1 << 32, win.data_ptr(), 1, out.data_ptr(),
+    rc = lib.pgt_het_reduce_dev(ctx._ctx, pos.data_ptr(), g.data_ptr(), 1 << 32, win.data_ptr(), 1, out.data_ptr(), out.numel(),
                                 tree.data_ptr(), tree.numel(), None)
     assert rc == _lib.PGT_EARG and b"2^32" in lib.pgt_last_error(ctx._ctx)  # refused before touching memory
     rc = lib.pgt_extreme_reduce_dev(ctx._ctx, pos.data_ptr(), a.data_ptr(), n, 7, 2.0, win.data_ptr(), 1, out.data_ptr(),
-                                    tree.data_ptr(), tree.numel(), None)
+                                    out.numel(), tree.data_ptr(), tree.numel(), None)
     assert rc == _lib.PGT_EARG  # unknown mode
+    # ABI 4: the C entry points themselves refuse rows that do not fit `out` (in peer mode `out` is another GPU's
+    # memory), before any launch — not only the Python wrapper
+    n_win = win.numel() // 32
+    b = torch.rand(n, dtype=torch.float64, device=dev)
+    big_tree = torch.empty(ctx.tree_bytes(_lib.PGT_STAT_DXY, n) + 2 * ctx.tree_bytes(_lib.PGT_STAT_HET, n), dtype=torch.uint8, device=dev)
+    canary = torch.full((n_win * 40 + 64,), 0xAB, dtype=torch.uint8, device=dev)
+    i32 = torch.ones(n, dtype=torch.int32, device=dev)
+    g8 = torch.zeros(n, dtype=torch.int8, device=dev)
+    short = n_win * 24 - 1  # one byte short even of the smallest row type
+    calls = [
+        lambda: lib.pgt_fst_reduce_dev(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), n, win.data_ptr(), n_win, canary.data_ptr(),
+                                       n_win * 40 - 1, big_tree.data_ptr(), big_tree.numel(), None),
+        lambda: lib.pgt_het_reduce_dev(ctx._ctx, pos.data_ptr(), g8.data_ptr(), n, win.data_ptr(), n_win, canary.data_ptr(), n_win * 32 - 1,
+                                       big_tree.data_ptr(), big_tree.numel(), None),
+        lambda: lib.pgt_dxy_reduce_dev(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), i32.data_ptr(), i32.data_ptr(), n, 1,
+                                       win.data_ptr(), n_win, canary.data_ptr(), short, None, big_tree.data_ptr(), big_tree.numel(), None),
+        lambda: lib.pgt_dxy_het_reduce_dev(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), i32.data_ptr(), i32.data_ptr(),
+                                           g8.data_ptr(), g8.data_ptr(), n, 1, win.data_ptr(), n_win, canary.data_ptr(), n_win * 24, None,
+                                           canary.data_ptr(), canary.data_ptr(), n_win * 32 - 1, big_tree.data_ptr(), big_tree.numel(), None),
+        lambda: lib.pgt_extreme_reduce_dev(ctx._ctx, pos.data_ptr(), b.data_ptr(), n, 0, 2.0, win.data_ptr(), n_win, canary.data_ptr(),
+                                           n_win * 32 - 1, big_tree.data_ptr(), big_tree.numel(), None),
+    ]
+    import ctypes as C
+    pa = (C.c_void_p * 2)(b.data_ptr(), b.data_ptr())
+    two_trees = torch.empty(2 * ctx.tree_bytes(_lib.PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
+    calls.append(lambda: lib.pgt_fst_reduce_pairs_dev(ctx._ctx, pos.data_ptr(), pa, pa, 2, n, win.data_ptr(), n_win, canary.data_ptr(),
+                                                      2 * n_win * 40 - 1, two_trees.data_ptr(), two_trees.numel(), None))
+    for k, call in enumerate(calls):
+        assert call() == _lib.PGT_EARG and b"do not fit" in lib.pgt_last_error(ctx._ctx), k
+    torch.cuda.synchronize()
+    assert bool((canary == 0xAB).all())  # nothing was launched
+    hrows = np.zeros(n_win, dtype=_lib.FST_ROW_DTYPE)
+    hwin = pgt.build_windows_sites(np.array([n], dtype=np.uint64), 1000, 500)
+    assert lib.pgt_fst_reduce_cols(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), n, hwin.ctypes.data, hwin.size,
+                                   hrows.ctypes.data, hrows.nbytes - 1) == _lib.PGT_EARG
+    assert lib.pgt_fst_reduce_cols(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), n, hwin.ctypes.data, hwin.size,
+                                   hrows.ctypes.data, hrows.nbytes) == _lib.PGT_OK
+    tab = ctx.window_table_sites(np.array([n], dtype=np.uint64), 1000, 500)
+    assert lib.pgt_fst_reduce_tab(ctx._ctx, pos.data_ptr(), b.data_ptr(), b.data_ptr(), n, 1, tab._h, hrows.ctypes.data,
+                                  hrows.nbytes - 1) == _lib.PGT_EARG
+    tab.free()
 
 
 def test_fst_beyond_2_32_sites(pgt, ctx):

@@ -195,7 +195,7 @@ def test_ingested_columns_feed_the_scan(pgt, ctx, oracle):
     rows = np.zeros(win.size, dtype=_lib.FST_ROW_DTYPE)
     lib = _lib.load()
     _lib.check(lib.pgt_fst_reduce_cols(ctx._ctx, ing.column(1).data_ptr(), ing.column(2).data_ptr(), ing.column(3).data_ptr(),
-                                       ing.rows, win.ctypes.data, win.size, rows.ctypes.data), ctx._ctx)
+                                       ing.rows, win.ctypes.data, win.size, rows.ctypes.data, rows.nbytes), ctx._ctx)
     ref = ctx.fst_reduce(pos, a, b, pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S))
     assert rows.tobytes() == ref.tobytes()
     assert C.sizeof(C.c_void_p) == 8
