@@ -467,45 +467,85 @@ int orc_dxy_text(const char *maf1, const char *maf2, const char *sizefile, uint3
     if (rc) { table_free(&t1); return rc; }
     uint32_t *run_len = NULL;
     orc_row *rows = NULL;
-    /* identical site sets only: the sole input class on which dxyWindow.cpp:315-331 is defined */
-    if (t1.n != t2.n || t1.n_runs != t2.n_runs) { rc = ORC_EDOMAIN; goto done; }
-    for (size_t r = 0; r < t1.n_runs; ++r)
-        if (strcmp(t1.run_name[r], t2.run_name[r])) { rc = ORC_EDOMAIN; goto done; }
-    for (size_t i = 0; i < t1.n; ++i)
-        if (t1.pos[i] != t2.pos[i] || t1.chr[i] != t2.chr[i]) { rc = ORC_EDOMAIN; goto done; }
+    table m; /* the synchronised sites: chr / pos / name from pop1 (dxyWindow.cpp:333,389), x = p1, y = p2, k / g = nInd 1 / 2 */
+    memset(&m, 0, sizeof m);
+    /* The two-file synchronisation of dxyWindow.cpp:315-331, restated literally on line indices i (pop1) and
+     * j (pop2): equal (position, chromosome NAME) -> a matched site; otherwise one file is advanced — pop1
+     * until its POSITION equals pop2's (names are not compared there, :319), or pop2 while its position is
+     * smaller (:326) — and the run ENDS (break out of the main loop, :323,:330) when that fails.  A failed
+     * getline leaves the last parsed site in place (:320,:327).  Identical and nested site sets give the
+     * intersection; anything else gives whatever these rules give, truncated output included. */
+    if (t1.n && t2.n) {
+        if (strcmp(t1.run_name[t1.chr[0]], t2.run_name[t2.chr[0]])) { rc = ORC_EDOMAIN; goto done; } /* :294-298 exit 255 */
+        size_t i = 0, j = 0;
+        const char *cur = t1.run_name[t1.chr[0]]; /* `chr`, :293 */
+        for (;;) {
+            const char *c1 = t1.run_name[t1.chr[i]], *c2 = t2.run_name[t2.chr[j]];
+            const int same = !strcmp(c1, c2);
+            if (t1.pos[i] != t2.pos[j] || !same) {
+                if ((same && t1.pos[i] < t2.pos[j]) || (!same && strcmp(c2, cur))) {
+                    while (t1.pos[i] != t2.pos[j]) {
+                        if (i + 1 >= t1.n) break;
+                        ++i;
+                    }
+                    if (t1.pos[i] != t2.pos[j]) break;
+                } else {
+                    while (t2.pos[j] < t1.pos[i]) {
+                        if (j + 1 >= t2.n) break;
+                        ++j;
+                    }
+                    if (t1.pos[i] != t2.pos[j]) break;
+                }
+            }
+            cur = t1.run_name[t1.chr[i]]; /* :333 */
+            if (table_grow(&m) || table_run(&m, cur, strlen(cur))) { rc = ORC_EIO; goto done; }
+            m.chr[m.n] = (uint32_t)(m.n_runs - 1);
+            m.pos[m.n] = t1.pos[i];
+            m.x[m.n] = t1.x[i];
+            m.y[m.n] = t2.x[j];
+            m.k[m.n] = t1.k[i];
+            m.g[m.n] = t2.k[j];
+            m.n++;
+            if (i + 1 >= t1.n) break; /* :399 */
+            ++i;
+            if (j + 1 >= t2.n) break; /* :402 */
+            ++j;
+        }
+    }
 
     uint64_t slots = 0;
     if (!fixedsite) { /* dxyWindow.cpp:155-170 + :338-343 */
         if (!sizefile) { rc = ORC_EARG; goto done; }
-        run_len = calloc(t1.n_runs ? t1.n_runs : 1, sizeof *run_len);
+        run_len = calloc(m.n_runs ? m.n_runs : 1, sizeof *run_len);
         FILE *sf = fopen(sizefile, "r");
         if (!sf || !run_len) { if (sf) fclose(sf); rc = ORC_EIO; goto done; }
         char name[4096];
         unsigned len;
         while (fscanf(sf, "%4095s %u", name, &len) == 2)
-            for (size_t r = 0; r < t1.n_runs; ++r)
-                if (!run_len[r] && !strcmp(name, t1.run_name[r])) run_len[r] = len; /* map::insert keeps the first */
+            for (size_t r = 0; r < m.n_runs; ++r)
+                if (!run_len[r] && !strcmp(name, m.run_name[r])) run_len[r] = len; /* map::insert keeps the first */
         fclose(sf);
-        for (size_t r = 0; r < t1.n_runs; ++r) {
+        for (size_t r = 0; r < m.n_runs; ++r) {
             if (!run_len[r]) { rc = ORC_EDOMAIN; goto done; }
             slots += run_len[r];
         }
     }
     size_t cap, nr = 0;
-    if (rows_alloc((size_t)(fixedsite ? t1.n : slots + t1.n), S, 2 * t1.n_runs, &rows, &cap)) { rc = ORC_EIO; goto done; }
+    if (rows_alloc((size_t)(fixedsite ? m.n : slots + m.n), S, 2 * m.n_runs, &rows, &cap)) { rc = ORC_EIO; goto done; }
     orc_dxy_total tot;
-    rc = orc_dxy_scan(t1.chr, t1.pos, t1.x, t2.x, t1.k, t2.k, t1.n, W, S, minind, fixedsite,
-                      skip_missing, run_len, t1.n_runs, rows, cap, &nr, &tot);
+    rc = orc_dxy_scan(m.chr, m.pos, m.x, m.y, m.k, m.g, m.n, W, S, minind, fixedsite,
+                      skip_missing, run_len, m.n_runs, rows, cap, &nr, &tot);
     if (rc == ORC_OK) {
         for (size_t i = 0; i < nr; ++i)
             if (rows[i].printed) /* dxyWindow.cpp:190 */
-                fprintf(out, "%s\t%u\t%u\t%g\t%u\t%u\n", t1.run_name[rows[i].label], rows[i].start,
+                fprintf(out, "%s\t%u\t%u\t%g\t%u\t%u\n", m.run_name[rows[i].label], rows[i].start,
                         rows[i].end, rows[i].value, rows[i].n, rows[i].nskip);
         fprintf(W == 0 ? out : err, "%g\t%u\t%u\n", tot.sum, tot.neff, tot.nskip); /* :429-433 */
     }
 done:
     free(rows);
     free(run_len);
+    table_free(&m);
     table_free(&t1);
     table_free(&t2);
     return rc;

@@ -15,9 +15,12 @@
  *   fst / het : byte-for-byte against oracle/_ref/{fstWindow,hetWindow} (the unmodified
  *               reference sources compiled by oracle/Makefile) on seeded random inputs and
  *               on the known-answer cases of SURVEY.md §4; fixtures in tests/golden/.
- *   dxy       : dxyWindow.cpp cannot be built in this image (needs Boost.Iostreams headers),
- *               so the dxy restatement is pinned ONLY by the four known-answer cases recorded
- *               in SURVEY.md §4 (tests/golden/dxy_kat.json).  "parity partially pinned".
+ *   dxy       : PARITY UNPINNED.  dxyWindow.cpp cannot be built in this image (it needs the
+ *               Boost.Iostreams headers, dxyWindow.cpp:17-19; stand-ins are not allowed) and the
+ *               reference holds no vectors.  tests/golden/dxy_kat.json (four cases recorded in
+ *               SURVEY.md §4) pins nothing by the rules of this build.  oracle/Makefile builds
+ *               _ref/dxyWindow wherever the real Boost exists and tests/golden/make_golden.py
+ *               then writes ref_dxy.json, which the tests consume: one command pins it there.
  *
  * The algorithm here is deliberately the reference's streaming one — a W-entry buffer that
  * is re-summed sequentially for every window and shifted left by S — and deliberately NOT
@@ -67,8 +70,8 @@ int orc_fst_scan(const uint32_t *chr, const uint32_t *pos, const double *a, cons
 int orc_het_scan(const uint32_t *chr, const uint32_t *pos, const int32_t *g,
                  size_t n, uint32_t W, uint32_t S, orc_row *out, size_t cap, size_t *n_out);
 
-/* Both populations already synchronised on identical sites (the only input class for which
- * dxyWindow.cpp:315-331 is well defined).  run_chr_len[r] = -sizefile length of the chromosome
+/* Both populations already synchronised (orc_dxy_text restates the two-file synchronisation of
+ * dxyWindow.cpp:315-331 itself and passes the matched sites on).  run_chr_len[r] = -sizefile length of the chromosome
  * of run r (ignored when fixedsite != 0).  W == 0 → global only (requires fixedsite). */
 int orc_dxy_scan(const uint32_t *chr, const uint32_t *pos, const double *p1, const double *p2,
                  const int32_t *n1, const int32_t *n2, size_t n, uint32_t W, uint32_t S,

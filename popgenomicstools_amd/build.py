@@ -63,9 +63,13 @@ def build_lib(force: bool = False) -> str:
     import fcntl
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
     deps = srcs + [os.path.join(CSRC, "pgt_internal.h"), os.path.join(CSRC, "pgt_device.h"), os.path.join(ROOT, "include", "pgtwin.h")]
-    extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPGT_TUNING_BUILD for tools/tune_build.py
-    if "-DPGT_TUNING_BUILD" in extra:  # rejected kernel variants, kept outside the product tree
-        deps.append(os.path.join(ROOT, "tools", "pgt_build_experiments.inc"))
+    extra = os.environ.get("PGT_EXTRA_HIPCC_FLAGS", "").split()
+    if "-DPGT_TUNING_BUILD" in extra:
+        # the tuning library (tools/tune_*.py): tools/pgt_kernels_tuning.hip REPLACES csrc/pgt_kernels.hip — it includes the
+        # product kernels textually and adds the measured-and-rejected variants; nothing under csrc/ knows about it
+        tuning = os.path.join(ROOT, "tools", "pgt_kernels_tuning.hip")
+        srcs = [tuning if os.path.basename(s) == "pgt_kernels.hip" else s for s in srcs]
+        deps += [tuning, os.path.join(ROOT, "tools", "pgt_build_experiments.inc")]
         extra = extra + ["-I" + os.path.join(ROOT, "tools")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + extra
     stamp = _stamp(flags, deps)

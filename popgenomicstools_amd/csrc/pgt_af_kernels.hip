@@ -137,7 +137,7 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 }
 
 // ---- BUILD: one wave per level-2 tile (64 pieces of 128 sites = 32 leaf nodes of 256) ---------------
-template <int NP, int ABLATE = 0, bool WIDE = true>  // ABLATE (tuning build only, wrong results): 1 no reduce-scatter, 2 no node stores, 3 no accumulate; WIDE = false: 128-site leaves, 64 per tile (timing only)
+template <int NP>
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     // profiles/r02/af_pipe.txt), two level-2 tiles staged per flush and / or three leaves prefetched (67.9-69.9
     // vs 69.7 %, af_stage2.txt) changed nothing; halving the bytes (256-site leaves) did.
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
-    double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * (WIDE ? kAfRadix1 : kRadix);
+    double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kAfRadix1;
 
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
@@ -183,29 +183,19 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
         for (int j = 0; j < kRadix; ++j) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
             double2 nxt[NP];
             if (j + 1 < kRadix) load_tile(nxt, j + 1);  // next piece's loads fly while this one is reduced
-            if (!WIDE || (j & (kAfPieces - 1)) == 0) {
+            if ((j & (kAfPieces - 1)) == 0) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) vals[v] = 0.0;
             }
             double fx[NP], fy[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
-            if constexpr (ABLATE != 3) {
-                af_accumulate<NP>(vals, fx);
-                af_accumulate<NP>(vals, fy);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NP; ++k) vals[k] = fx[k] + fy[k];
-            }
-            if (!WIDE || (j & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
-                if constexpr (ABLATE != 1) {
-                    rs_steps<V, 0>(vals, lane);
-                } else {  // keeps every value (and every load) alive without any cross-lane step
-#pragma unroll
-                    for (int v = 1; v < V; ++v) vals[0] += vals[v];
-                }
+            af_accumulate<NP>(vals, fx);
+            af_accumulate<NP>(vals, fy);
+            if ((j & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
+                rs_steps<V, 0>(vals, lane);
                 if (my >= 0) {
-                    stage[(WIDE ? j / kAfPieces : j) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
+                    stage[(j / kAfPieces) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
                     l2acc += vals[0];
                 }
             }
@@ -213,11 +203,10 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
         }
         if (my >= 0) *af_node<V>(tv, 1, my, t) = l2acc;  // the level-2 node: V consecutive doubles, one 8*V-byte run
-        if constexpr (ABLATE == 2) continue;
         // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
         // (the stage belongs to this wave alone, LDS operations of a wave complete in order: no barrier)
         {
-            constexpr int kNodes = WIDE ? kAfRadix1 : kRadix;
+            constexpr int kNodes = kAfRadix1;
             double2 *dst = reinterpret_cast<double2 *>(af_node<V>(tv, 0, 0, t * kNodes));
             const double2 *src = reinterpret_cast<const double2 *>(stage);
             constexpr int kVec = V * kNodes / 2;  // double2 elements of the block
@@ -346,24 +335,12 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         // so every wave does r tiles.  Measured at 10^8 sites, 8 populations (profiles/r02/af_caps.txt): the
         // unbalanced 2048-workgroup grid of round 1 (12207 tiles over 8192 waves: half the waves do 2 tiles,
         // half 1) 68-69 % of the HBM peak, balanced 74.9 %; caps of 512 / 1024 workgroups 70.8 / 74.0 %.
-        uint64_t cap = NP == 2 ? 512 : 2048;
-#ifdef PGT_TUNING_BUILD
-        if (const char *capenv = getenv("PGT_AF_CAP")) cap = (uint64_t)atoi(capenv);
-#endif
+        const uint64_t cap = NP == 2 ? 512 : 2048;
         const uint64_t max_waves = cap * 4;
         const uint64_t rounds = (tl.count[1] + max_waves - 1) / max_waves;
         const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
         uint64_t blocks = (waves + 3) / 4;
         constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x 32 nodes x V doubles
-#ifdef PGT_TUNING_BUILD
-        const char *ab = getenv("PGT_AF_ABLATE");
-        const int abl = ab ? atoi(ab) : 0;
-        if (abl == 1) hipLaunchKernelGGL((af_build_kernel<NP, 1>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
-        else if (abl == 2) hipLaunchKernelGGL((af_build_kernel<NP, 2>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
-        else if (abl == 3) hipLaunchKernelGGL((af_build_kernel<NP, 3>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
-        else if (abl == 20) hipLaunchKernelGGL((af_build_kernel<NP, 0, false>), dim3((unsigned)blocks), dim3(256), 2 * kStage, s, cols, n, tl.count[1], tv);
-        else
-#endif
         hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
         for (int k = 2; k < tv.n_levels; ++k) {
@@ -391,10 +368,6 @@ template <int NP>
 void af_allow_lds() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double)));
-#ifdef PGT_TUNING_BUILD
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)4 * Shape<NP>::kVals * kRadix * sizeof(double)));
-#endif
 }
 }  // namespace
 

@@ -94,11 +94,7 @@ struct AfTree {
 };
 // the AF tree's level 1 holds 32 nodes of 256 sites per level-2 node (pgt_af_kernels.hip), half of the f64 layout's count
 inline size_t af_level_bytes(const TreeLayout &t, int k, int n_vals) {
-#ifdef PGT_TUNING_BUILD
-    const uint64_t nodes = t.count[k];  // room for the 128-site-leaf variant of tools/ablate_af_stores.py
-#else
     const uint64_t nodes = k == 0 ? t.count[0] / 2 : t.count[k];
-#endif
     return ((nodes * (size_t)n_vals * 8 + 255) / 256) * 256;
 }
 inline size_t af_tree_bytes(const TreeLayout &t, int n_vals) {

@@ -22,8 +22,6 @@
 // Memory-bound: 2 f64 adds per 16 B, no contraction to feed MFMA (none is used).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "pgt_device.h"
 #include "pgt_internal.h"
 
@@ -1085,10 +1083,6 @@ inline int record(void *ev, hipStream_t s, std::string *err) {
     return hip_fail(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord", err);
 }
 
-#ifdef PGT_TUNING_BUILD
-#include "pgt_build_experiments.inc"
-#endif
-
 // ------------------------------------------------------------------------------------------
 // The site-window table written on the device from the per-run plan (pgt_windows.cpp: plan_entry_windows /
 // for_each_window are the host form of exactly this): thread i finds its run by bisection over the runs'
@@ -1168,9 +1162,29 @@ int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function
     return PGT_OK;
 }
 
-int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
-               uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
-               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints) {
+// The streaming build launch of the fst tree (levels 1 and 2 of `np` pairs).
+// Loads in flight per lane: 8 (UNROLL 4) for long inputs; 16 (UNROLL 8) below ~3e8 sites, where the
+// fixed cost of a launch shows: the last tile of every wave runs latency-bound (16 dependent
+// batches of 8 loads, ~1 us each), with 16 in flight it is half as long.  Measured fit t = t0 +
+// bytes/BW: t0 12.0 -> 9.9 us; +1.5 % at 1e8, +1.8 % at 1.25e8, -0.4 % at 1e9 sites
+// (profiles/r02/size_sweep_variants.md).  The arithmetic order does not depend on it: same bits.
+namespace {
+void fst_build_launch(hipStream_t s, const PairCols &cols, uint32_t np, uint64_t n, const TreeLayout &tl, const TreeView &tv) {
+    const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks), np);
+    if (tl.count[1] * np <= kFstSmallTiles)
+        hipLaunchKernelGGL((fst_build_kernel<kFstStage, 8, true>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv,
+                           (uint64_t)0);
+    else
+        hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
+}
+
+// launch_fst with the build launch as a parameter: the product passes fst_build_launch; tools/pgt_kernels_tuning.hip
+// (a separate translation unit that textually includes this file, never part of the product build) passes
+// its experiments.  No preprocessor switch lives in this file.
+template <class BuildFn>
+int launch_fst_with(BuildFn build, const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
+                    uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
+                    void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_FST, n);
     const int levels = useful_levels(tl, PGT_STAT_FST, hints.max_window);
@@ -1181,24 +1195,7 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         const TreeView tv = make_view(tl, static_cast<char *>(tree) + (size_t)p0 * tl.bytes, tl.bytes, levels);
         if (p0 == 0) if (int rc = record(ev_build0, s, err)) return rc;
         if (n > 0) {
-            bool launched = false;
-#ifdef PGT_TUNING_BUILD  // tools/tune_*.py, tools/ablate_*.py: never defined in the product build
-            launched = launch_fst_experiment(s, cols, np, n, tl, tv);
-#endif
-            if (!launched) {
-                // Loads in flight per lane: 8 (UNROLL 4) for long inputs; 16 (UNROLL 8) below ~3e8 sites, where the
-                // fixed cost of a launch shows: the last tile of every wave runs latency-bound (16 dependent
-                // batches of 8 loads, ~1 us each), with 16 in flight it is half as long.  Measured fit t = t0 +
-                // bytes/BW: t0 12.0 -> 9.9 us; +1.5 % at 1e8, +1.8 % at 1.25e8, -0.4 % at 1e9 sites
-                // (profiles/r02/size_sweep_variants.md).  The arithmetic order does not depend on it: same bits.
-                const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks), np);
-                if (tl.count[1] * np <= kFstSmallTiles)
-                    hipLaunchKernelGGL((fst_build_kernel<kFstStage, 8, true>), grid, dim3(256), kFstStageBytes, s, cols, n,
-                                       tl.count[1], tv, (uint64_t)0);
-                else
-                    hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv,
-                                       (uint64_t)0);
-            }
+            build(s, cols, np, n, tl, tv);
             if (int rc = hip_fail(hipGetLastError(), "fst_build_kernel", err)) return rc;
             if (int rc = launch_upper<NodeFst>(tl, tv, np, s, err)) return rc;
         }
@@ -1216,6 +1213,14 @@ int launch_fst(const uint32_t *pos, const double *const *a, const double *const 
         }
     }
     return record(ev_query1, s, err);
+}
+}  // namespace
+
+int launch_fst(const uint32_t *pos, const double *const *a, const double *const *b, uint32_t n_pairs,
+               uint64_t n, const pgt_win *win, uint64_t n_win, pgt_fst_row *out, void *tree, void *stream,
+               void *ev_build0, void *ev_build1, void *ev_query1, std::string *err, const Hints &hints) {
+    return launch_fst_with(fst_build_launch, pos, a, b, n_pairs, n, win, n_win, out, tree, stream, ev_build0, ev_build1, ev_query1,
+                           err, hints);
 }
 
 int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win, uint64_t n_win,
@@ -1285,42 +1290,30 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
 
 // grid = exactly the workgroups that are resident together (LDS-limited), so that all waves run in near
 // lockstep and their staged node rows are flushed at about the same times (see NodeStage)
+namespace {
 template <int STAGE, int UNROLL, bool DEFER>
 void launch_ext_variant(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv, unsigned cap) {
     const size_t lds = DEFER ? (size_t)4 * STAGE * 1024 : 0;
     hipLaunchKernelGGL((ext_build_kernel<STAGE, UNROLL, DEFER>), dim3(build_grid(n_l2, cap)), dim3(256), lds, s, g, n, n_l2, tv);
 }
-void launch_ext_build(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv) {
-#ifdef PGT_TUNING_BUILD  // tools/tune_ext.py: A/B of the stage depth / occupancy / loads in flight
-    static const int variant = getenv("PGT_EXT_VARIANT") ? atoi(getenv("PGT_EXT_VARIANT")) : 0;
-    const char *e = getenv("PGT_EXT_VARIANT_NOW");  // re-read per call for interleaved A/B in one process
-    const int v = e ? atoi(e) : variant;
-    switch (v) {
-        case 1: return launch_ext_variant<8, 4, false>(s, g, n, n_l2, tv, 2048);
-        case 2: return launch_ext_variant<8, 4, true>(s, g, n, n_l2, tv, 1024);
-        case 3: return launch_ext_variant<4, 4, true>(s, g, n, n_l2, tv, 2048);
-        case 4: return launch_ext_variant<8, 8, true>(s, g, n, n_l2, tv, 1024);
-        case 5: return launch_ext_variant<8, 2, true>(s, g, n, n_l2, tv, 1024);
-        case 6: return launch_ext_variant<8, 8, false>(s, g, n, n_l2, tv, 2048);
-        default: break;
-    }
-#endif
-    if (n_l2 <= kFstSmallTiles / 2)  // 16 loads in flight per lane for short inputs (see launch_fst); ext tiles are 16384 sites
+void ext_build_launch(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv) {
+    if (n_l2 <= kFstSmallTiles / 2)  // 16 loads in flight per lane for short inputs (see fst_build_launch); ext tiles are 16384 sites
         launch_ext_variant<kExtStage, 8, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
     else
         launch_ext_variant<kExtStage, 4, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
 }
 
-int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
-               uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
-               void *ev_query1, std::string *err, const Hints &hints) {
+template <class BuildFn>  // the build launch is a parameter for the same reason as in launch_fst_with
+int launch_ext_with(BuildFn build, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
+                    uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
+                    void *ev_query1, std::string *err, const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_EXT, n);
     const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_EXT, hints.max_window));
     const double thr = mode == PGT_EXT_XP_MIN ? -cutoff : cutoff;  // s < cutoff  <=>  -s > -cutoff
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        launch_ext_build(s, ExtBuildArgs{score, mode, thr}, n, tl.count[1], tv);
+        build(s, ExtBuildArgs{score, mode, thr}, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "ext_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeExt>(tl, tv, 1, s, err)) return rc;
     }
@@ -1332,6 +1325,14 @@ int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, d
         if (int rc = hip_fail(hipGetLastError(), "query_kernel<ext>", err)) return rc;
     }
     return record(ev_query1, s, err);
+}
+}  // namespace
+
+int launch_ext(const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff, const pgt_win *win,
+               uint64_t n_win, pgt_ext_row *out, void *tree, void *stream, void *ev_build0, void *ev_build1,
+               void *ev_query1, std::string *err, const Hints &hints) {
+    return launch_ext_with(ext_build_launch, pos, score, n, mode, cutoff, win, n_win, out, tree, stream, ev_build0, ev_build1,
+                           ev_query1, err, hints);
 }
 
 int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,

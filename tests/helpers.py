@@ -99,3 +99,36 @@ def write_bgzf(path, data: bytes, block=0xff00, level=6):
         out += d + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c))
     with open(path, "wb") as fh:
         fh.write(bytes(out))
+
+
+def dxy_ref_cases(tmp_path, plain_text=False):
+    """The reference-made dxyWindow fixtures (tests/golden/ref_dxy.json: written by make_golden.py only on an image
+    with the real Boost.Iostreams, where oracle/Makefile builds the unmodified dxyWindow.cpp).  None when absent —
+    the dxy oracle is then "parity unpinned".  Yields (case, argv tail with real paths, options dict); with
+    plain_text the gzip members are inflated first (the oracle's text front end reads plain text only)."""
+    import base64
+    import gzip
+    path = os.path.join(GOLDEN, "ref_dxy.json")
+    if not os.path.exists(path):
+        return None
+    out = []
+    for k, c in enumerate(json.load(open(path))["cases"]):
+        d = tmp_path / f"dxyref{k}"
+        d.mkdir()
+        names = {}
+        for name, b64 in c["files"].items():
+            raw = base64.b64decode(b64)
+            if plain_text and name.endswith(".gz"):
+                raw, new = gzip.decompress(raw), name[:-3]
+            else:
+                new = name
+            (d / new).write_bytes(raw)
+            names["@" + name] = str(d / new)
+        argv = [names.get(a, a) for a in c["args"]]
+        opt = {"winsize": 0, "stepsize": 0, "minind": 1, "fixedsite": 0, "skip_missing": 0, "sizefile": None}
+        for i in range(0, len(argv) - 2, 2):
+            key = argv[i].lstrip("-")
+            opt[key] = argv[i + 1] if key == "sizefile" else int(argv[i + 1])
+        opt["maf1"], opt["maf2"] = argv[-2], argv[-1]
+        out.append((c, argv, opt))
+    return out

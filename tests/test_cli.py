@@ -150,6 +150,22 @@ def test_dxy_cli_known_answers(hosts, tmp_path, gz):
 
 
 @pytest.mark.gpu
+def test_dxy_cli_against_reference_made_cases(hosts, tmp_path):
+    """The GPU host against the unmodified reference dxyWindow's recorded runs (gzip members included), when the
+    fixture exists (an image with Boost; see tests/golden/make_golden.py): coordinates, counts, labels and the exit
+    code exact, the dxy column within 1e-9 + the 6-digit print."""
+    cases = helpers.dxy_ref_cases(tmp_path)
+    if cases is None:
+        pytest.skip("tests/golden/ref_dxy.json absent (no Boost in this image): dxy parity unpinned")
+    for c, argv, _ in cases:
+        r = run([hosts["dxyWindow"]] + argv)
+        assert r.returncode == (0 if c["rc"] == 0 else 255), (c["args"], r.stderr)
+        if c["rc"] == 0:
+            tsv_equal(r.stdout, c["stdout"], 3)
+            tsv_equal(r.stderr, c["stderr"], 0)
+
+
+@pytest.mark.gpu
 def test_dxy_cli_intersects_site_sets(hosts, tmp_path, oracle):
     """pop2 lists extra sites (nested set): rows equal the oracle run on the shared sites."""
     rng = np.random.default_rng(4)

@@ -223,6 +223,47 @@ def test_dxy_vs_oracle_random(pgt, ctx, oracle, fixedsite):
                   np.array(len_l, dtype=np.uint32))
 
 
+def test_dxy_rows_against_reference_made_cases(pgt, ctx, tmp_path):
+    """The C-ABI rows (pgt_build_windows_* + pgt_dxy_reduce) against the unmodified reference dxyWindow's recorded
+    stdout / genome-wide line, for the fixture cases whose two MAF files list the same sites (the column interface
+    takes synchronised populations; nested sets go through the CLI test).  Skipped where the fixture cannot exist."""
+    cases = helpers.dxy_ref_cases(tmp_path, plain_text=True)
+    if cases is None:
+        pytest.skip("tests/golden/ref_dxy.json absent (no Boost in this image): dxy parity unpinned")
+
+    def maf(path):
+        rows = [ln.split() for ln in open(path).read().splitlines()[1:] if ln.strip()]
+        return [r[0] for r in rows], np.array([int(r[1]) for r in rows], np.uint32), np.array([float(r[5]) for r in rows]), \
+            np.array([int(r[6]) for r in rows], np.int32)
+    used = 0
+    for c, argv, o in cases:
+        if c["rc"] != 0:
+            continue
+        (c1, q1, f1, k1), (c2, q2, f2, k2) = maf(o["maf1"]), maf(o["maf2"])
+        if c1 != c2 or not np.array_equal(q1, q2):
+            continue
+        names = [c1[0]] + [b for a, b in zip(c1, c1[1:]) if a != b]
+        chr_ids = np.cumsum([0] + [int(a != b) for a, b in zip(c1, c1[1:])]).astype(np.uint32)
+        chr_len = None
+        if not o["fixedsite"]:
+            sizes = {}
+            for ln in open(o["sizefile"]):
+                sizes.setdefault(ln.split()[0], int(ln.split()[1]))  # first entry of a name wins (std::map::insert)
+            chr_len = np.array([sizes[nm] for nm in names], np.uint32)
+        res = pgt.dxy_window(chr_ids, q1, f1, f2, k1, k2, o["winsize"], o["stepsize"], o["minind"], o["fixedsite"], chr_len,
+                             o["skip_missing"], ctx=ctx)
+        tsv = helpers.parse_tsv(c["stdout"] if o["winsize"] else "")
+        assert len(tsv) == res.rows.size, c["args"]
+        for r, w, t in zip(res.rows, res.win, tsv):
+            assert names[int(w["label_run"])] == t[0] and int(r["start"]) == int(t[1]) and int(r["end"]) == int(t[2])
+            assert int(r["neff"]) == int(t[4]) and int(r["nskip"]) == int(t[5])
+            assert abs(float(r["sum"]) - float(t[3])) <= 1e-9 * abs(float(t[3])) + 5e-6 * max(abs(float(t[3])), 1e-4)
+        g = (c["stderr"] if o["winsize"] else c["stdout"]).split()
+        assert int(res.total["neff"]) == int(g[1]) and int(res.total["nskip"]) == int(g[2])
+        used += 1
+    assert used >= 20
+
+
 def test_dxy_large_and_global(pgt, ctx, oracle):
     rng = np.random.default_rng(8)
     n = 400_000

@@ -86,6 +86,79 @@ def test_dxy_known_answers(oracle, tmp_path):
         assert e.read_text() == c["stderr"]
 
 
+def test_dxy_reference_made_cases(oracle, tmp_path):
+    """THE PIN of the dxy restatement, where it exists: stdout, the stderr genome-wide line and the exit code of the
+    unmodified reference dxyWindow (both window modes, -minind, -skip_missing, nested site sets, gzip input), byte
+    for byte.  Needs tests/golden/ref_dxy.json, which only an image with the real Boost.Iostreams can produce
+    (oracle/Makefile + tests/golden/make_golden.py); this image has none, so here the test reports that as a skip."""
+    cases = helpers.dxy_ref_cases(tmp_path, plain_text=True)
+    if cases is None:
+        pytest.skip("tests/golden/ref_dxy.json absent: dxyWindow.cpp is unbuildable here (no Boost) — dxy parity unpinned")
+    assert len(cases) >= 100
+    for c, argv, o in cases:
+        out, err = tmp_path / "o.txt", tmp_path / "e.txt"
+        rc = oracle.dxy_text(o["maf1"], o["maf2"], o["sizefile"], o["winsize"], o["stepsize"], o["minind"], o["fixedsite"],
+                             o["skip_missing"], str(out), str(err))
+        if c["rc"] != 0:
+            assert rc != 0, c["args"]
+            continue
+        assert rc == 0, c["args"]
+        assert out.read_text() == c["stdout"], c["args"]
+        assert err.read_text() == c["stderr"], c["args"]
+
+
+def test_dxy_two_file_sync_restatement(oracle, tmp_path):
+    """The oracle restates the two-file synchronisation of dxyWindow.cpp:315-331 literally (UNPINNED like the rest of
+    the dxy path: no reference-made fixture exists in this image).  What can be checked without the reference:
+    (i) on nested site sets (pop2's sites a subset of pop1's — the inputs make_golden.dxy_case generates for the
+    future pin) the result is that of the two files cut down to their shared sites; (ii) a case walked by hand through
+    the reference lines: pop2 lists an extra site at the END of a chromosome that pop1 lacks -> at the chromosome
+    change pop1 is at (cB,3), pop2 still at (cA,9): names differ, pop2's name is the current chromosome, so :325-330
+    tries to advance pop2 while 9 < 3 — it does not — and the main loop breaks: cB is never processed."""
+    import gzip
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    rng = random.Random(5)
+    nested = 0
+    for k in range(120):
+        files, args = make_golden.dxy_case(rng)
+        d = tmp_path / f"c{k}"
+        d.mkdir()
+        path = {}
+        for name, raw in files.items():
+            plain = name[:-3] if name.endswith(".gz") else name
+            (d / plain).write_bytes(gzip.decompress(raw) if name.endswith(".gz") else raw)
+            path["@" + name] = str(d / plain)
+        argv = [path.get(a, a) for a in args]
+        o = {"winsize": 0, "stepsize": 0, "minind": 1, "fixedsite": 0, "skip_missing": 0, "sizefile": None}
+        for i in range(0, len(argv) - 2, 2):
+            o[argv[i].lstrip("-")] = argv[i + 1] if argv[i] == "-sizefile" else int(argv[i + 1])
+        l1, l2 = open(argv[-2]).read().splitlines(), open(argv[-1]).read().splitlines()
+        k1, k2 = {tuple(x.split()[:2]) for x in l1[1:]}, {tuple(x.split()[:2]) for x in l2[1:]}
+        nested += k1 != k2
+        (d / "s1").write_text("\n".join([l1[0]] + [x for x in l1[1:] if tuple(x.split()[:2]) in k2]) + "\n")
+        (d / "s2").write_text("\n".join([l2[0]] + [x for x in l2[1:] if tuple(x.split()[:2]) in k1]) + "\n")
+        outs = []
+        for m1, m2 in ((argv[-2], argv[-1]), (str(d / "s1"), str(d / "s2"))):
+            out, err = d / "o", d / "e"
+            assert oracle.dxy_text(m1, m2, o["sizefile"], o["winsize"], o["stepsize"], o["minind"], o["fixedsite"],
+                                   o["skip_missing"], str(out), str(err)) == 0, args
+            outs.append((out.read_text(), err.read_text()))
+        assert outs[0] == outs[1], args
+    assert nested >= 30
+    hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd\n"
+    (tmp_path / "a").write_text(hdr + "cA\t2\tA\tC\tA\t0.5\t4\ncA\t5\tA\tC\tA\t0.25\t4\ncB\t3\tA\tC\tA\t0.1\t4\n")
+    (tmp_path / "b").write_text(hdr + "cA\t2\tA\tC\tA\t0.5\t4\ncA\t5\tA\tC\tA\t0.75\t4\ncA\t9\tA\tC\tA\t0.3\t4\ncB\t3\tA\tC\tA\t0.9\t4\n")
+    out, err = tmp_path / "o", tmp_path / "e"
+    assert oracle.dxy_text(str(tmp_path / "a"), str(tmp_path / "b"), None, 1, 1, 1, 1, 0, str(out), str(err)) == 0
+    assert out.read_text() == "cA\t2\t2\t0.5\t1\t0\ncA\t5\t5\t0.625\t1\t0\n" and err.read_text() == "1.125\t2\t0\n"
+    # the mirror image (the extra site is in pop1): pop1 is advanced until its POSITION matches (:318-323) -> all sites match
+    assert oracle.dxy_text(str(tmp_path / "b"), str(tmp_path / "a"), None, 1, 1, 1, 1, 0, str(out), str(err)) == 0
+    assert [ln.split("\t")[:2] for ln in out.read_text().splitlines()] == [["cA", "2"], ["cA", "5"], ["cB", "3"]]
+
+
 def test_oracle_rejects_out_of_domain(oracle):
     z = np.zeros(3, dtype=np.uint32)
     d = np.zeros(3)
