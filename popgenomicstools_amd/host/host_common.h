@@ -26,6 +26,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,7 +98,12 @@ struct PhaseTimer {
 // End of a successful run: everything is printed, so skip the teardown (unmapping gigabytes of input
 // text and columns, destroying the HIP runtime: 0.1-0.3 s at 10^8 lines that no user is waiting for).
 [[noreturn]] inline void finish(PhaseTimer &timer) {
-    std::fflush(stdout);
+    // a failed write (ENOSPC, EPIPE, closed pipe) must not look like success: the TSV would be truncated with exit status 0
+    if (std::fflush(stdout) != 0 || std::ferror(stdout)) {
+        std::fprintf(stderr, "Error writing the output: %s\n", std::strerror(errno));
+        std::fflush(stderr);
+        _exit(255);
+    }
     timer.lap("print");
     if (timer.on) std::fprintf(stderr, "[pgt-host] %-14s %9.3f ms\n", "total", process_age_ms());
     std::fflush(stderr);

@@ -92,6 +92,19 @@ def tsv_equal(mine, ref, float_col):
 
 
 @pytest.mark.gpu
+def test_failed_output_write_is_not_a_success(hosts, tmp_path):
+    """A TSV that could not be written (disk full, closed pipe) must not end with exit status 0: /dev/full fails every
+    write with ENOSPC."""
+    src = tmp_path / "in.txt"
+    src.write_text("".join(f"c1\t{i}\t0.1\t0.2\n" for i in range(1, 3000)))
+    with open("/dev/full", "w") as full:
+        r = subprocess.run([hosts["fstWindow"], str(src), "5", "1"], stdout=full, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 255 and "rror" in r.stderr, (r.returncode, r.stderr)
+    ok = run([hosts["fstWindow"], str(src), "5", "1"])
+    assert ok.returncode == 0 and len(ok.stdout.splitlines()) == 2995
+
+
+@pytest.mark.gpu
 def test_fst_het_cli_against_reference_goldens(hosts, tmp_path):
     cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"]
     exact = 0

@@ -407,6 +407,58 @@ def test_full_size_properties(pgt, ctx):
     assert_close([rt["asum"].sum()], [float(a.sum())], "cover asum")
 
 
+@pytest.mark.timeout(1200)
+def test_config3_exact_workload_sharded_eight_ways(pgt, ctx, oracle):
+    """BASELINE configs[3] in its stated shape — fstWindow, ONE genome of 10^9 sites in 40 chromosomes, W = 50000, S = 10000,
+    the 8-way pgt_plan_shards plan of the 8-GPU run — on the one GPU: (i) the eight shards, each reduced from its own
+    column range [site_lo, site_hi) with its re-based table, give concatenated the bytes of the single-GPU table;
+    (ii) the windows inside the first 5x10^7 sites against the oracle's streaming machine (fstWindow.cpp:109-155
+    restated) at 1e-9, coordinates and counts exact; (iii) coordinates / n of all 99 996 rows against pos and the table."""
+    import torch
+    from synth_genome import SynthGenome
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free HBM")
+    n, n_chr, W, S = 1_000_000_000, 40, 50_000, 10_000
+    g = SynthGenome(12345, n, n_chr)
+    win = pgt.build_windows_sites(g.run_len, W, S)
+    assert win.size == 99_996
+    pos, a, b = g.fst_columns_t(0, n, dev)
+    with ctx.hints(W, S):
+        single = rows_from_device(ctx.fst_reduce_dev(pos, a, b, windows_to_device(win, dev))[0], FST_ROW_DTYPE)
+        # (i) the 8-GPU plan, shard by shard
+        shards = pgt.plan_shards(win, 8)
+        parts = []
+        for s_ in shards:
+            lo, hi = int(s_["site_lo"]), int(s_["site_hi"])
+            local = np.array(win[int(s_["win_begin"]): int(s_["win_end"])], dtype=WIN_DTYPE, copy=True)
+            local["lo"] -= np.uint64(lo)
+            local["hi"] -= np.uint64(lo)
+            assert lo % 65536 == 0 and 0.9 * n / 8 < hi - lo < 1.1 * n / 8 + 2 * W
+            parts.append(rows_from_device(ctx.fst_reduce_dev(pos[lo:hi], a[lo:hi], b[lo:hi], windows_to_device(local, dev))[0],
+                                          FST_ROW_DTYPE))
+    assert np.concatenate(parts).tobytes() == single.tobytes()
+    # (iii) coordinates and counts of every row
+    lo_t = torch.from_numpy(win["lo"].astype(np.int64)).to(dev)
+    hi_t = torch.from_numpy(win["hi"].astype(np.int64)).to(dev)
+    start = pos[lo_t].cpu().numpy().view(np.uint32)
+    end = pos[hi_t - 1].cpu().numpy().view(np.uint32)
+    assert np.array_equal(single["start"], start) and np.array_equal(single["end"], end)
+    assert np.array_equal(single["mid"], ((start.astype(np.uint64) + end) % 2**32 // 2).astype(np.uint32))
+    assert np.array_equal(single["n"], (win["hi"] - win["lo"]).astype(np.uint32))
+    # (ii) the prefix against the oracle (the reference's own streaming loop, restated and pinned for fst)
+    m = 50_000_000
+    per = n // n_chr
+    assert m % per == 0  # the prefix ends on a chromosome boundary: its windows are exactly the table's windows with hi <= m
+    ref = oracle.fst_scan(g.chr_ids_np(0, m), pos[:m].cpu().numpy().view(np.uint32), a[:m].cpu().numpy(), b[:m].cpu().numpy(), W, S)
+    k = int(np.searchsorted(win["hi"], m, side="right"))
+    assert ref.size == k >= 4900 and np.all(win["hi"][:k] <= m)
+    for f, r in (("start", "start"), ("end", "end"), ("mid", "mid"), ("n", "n")):
+        assert np.array_equal(single[f][:k], ref[r]), f
+    assert_close(single["fst"][:k], ref["value"], "fst vs oracle on the 5e7-site prefix")
+
+
 def test_fused_dxy_het_equals_separate_bitwise(pgt, ctx, oracle):
     """BASELINE config 3 entry point: same bytes as the three separate reductions, and the oracle's
     counts."""
