@@ -343,22 +343,143 @@ __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const 
 }
 
 // BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
-// window table.  One launch builds all three trees: blockIdx.y = 0 dxy, 1 and 2 the genotype
-// columns.  26 B/site streamed (p1,p2 f64 + n1,n2 i32 + g1,g2 i8).
+// window table — ONE stream of 26 B/site (p1,p2 f64 + n1,n2 i32 + g1,g2 i8).  The wave that owns level-2
+// tile t of the dxy tree (8192 sites) also owns the SAME 8192 sites of both genotype columns: that is
+// exactly one het work item (8 leaf tiles of 1024 sites, 8 KiB per column).  Its 16 genotype loads (one
+// 16-byte load per lane each) ride along with the 16 batches of dxy loads, one per batch, so they are in
+// flight together with 16 dxy loads and cost no round trip of their own; the byte counts go through the
+// same packed-word popcounts as het_build_body and ONE wave reduction per leaf (nonmissing and nhet packed
+// into one register: both are at most 1024).  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
+// LDS stage beside the tile's dxy row and leave with it (deferred stores, see NodeStage); level 2 of the het
+// trees comes from tree_up_kernel as in the separate build.  Node values and tree layout are those of the
+// separate kernels bit for bit (integer counts; the dxy arithmetic is the same code).
+// (Round 2 had a CONCATENATION here: blockIdx.y = 0 ran the dxy body, 1 and 2 the het body — the het
+// workgroups were scheduled behind the resident dxy ones and ran alone at the tail, every workgroup reserved
+// 64 KiB of LDS whether it used it or not: 1.5 % SLOWER than the three separate launches.)
 struct DxyHetBuildArgs {
     const double *p1, *p2;
     const int32_t *n1, *n2;
     const int8_t *g[2];
     uint64_t n;
     int minind;
-    uint64_t n_l2_dxy, n_items_het;
-    TreeView tv_dxy, tv_het[2];
+    uint64_t n_l2_dxy;
+    TreeView tv_dxy, tv_het;  // tv_het: the two genotype trees, pair_stride apart
 };
-template <int U = 2>
+constexpr size_t kDxyHetStageBytes = kFstStageBytes + (size_t)4 * kFstStage * 2 * kHetChunk * sizeof(NodeHet);  // + 2 KiB per wave
+
+__device__ __forceinline__ uint32_t het_count_packed(const uint4 &w) {  // nonmissing | nhet << 16 of 16 genotypes
+    uint32_t nm = 0, nh = 0;
+    het_count_word(w.x, nm, nh);
+    het_count_word(w.y, nm, nh);
+    het_count_word(w.z, nm, nh);
+    het_count_word(w.w, nm, nh);
+    return nm | (nh << 16);
+}
+
+template <int U = 4>  // dxy leaf tiles per batch; 64 / U batches per tile must cover the 16 genotype loads (U <= 4)
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
+    static_assert(kRadix / U >= 2 * kHetChunk, "one genotype load per batch");
+    static_assert((uint64_t)kLeafF64 * kRadix == (uint64_t)kLeafI8 * kHetChunk, "a dxy level-2 tile is one het work item");
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
-    if (blockIdx.y == 0) dxy_build_body<U>(f.p1, f.p2, f.n1, f.n2, f.n, f.minind, f.n_l2_dxy, f.tv_dxy, lds_stage);
-    else het_build_body(f.g[blockIdx.y - 1], f.n, f.n_items_het, f.tv_het[blockIdx.y - 1]);
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n = f.n;
+    NodeDxy *__restrict__ l1 = reinterpret_cast<NodeDxy *>(f.tv_dxy.base + f.tv_dxy.off[0]);
+    NodeDxy *__restrict__ l2 = reinterpret_cast<NodeDxy *>(f.tv_dxy.base + f.tv_dxy.off[1]);
+    constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;  // 8192 sites
+    NodeStage<NodeDxy, kFstStage, true> stage(lds_stage, wib, lane, l1, l2, n_waves);
+    // het side of the stage: [tile of the stage][column][leaf] behind the four waves' dxy rows
+    NodeHet *hstage = reinterpret_cast<NodeHet *>(lds_stage + kFstStageBytes) + (size_t)wib * kFstStage * 2 * kHetChunk;
+    int hheld = 0;
+    uint64_t hfirst = 0;
+    auto hflush = [&]() {
+        // 16 lanes: column = lane / 8, leaf = lane % 8 -> one 64-byte run per column and tile
+        for (int k = 0; k < hheld; ++k) {
+            const uint64_t t = hfirst + (uint64_t)k * n_waves;
+            if (lane < 2 * kHetChunk) {
+                NodeHet *dst = reinterpret_cast<NodeHet *>(f.tv_het.base + (size_t)(lane >> 3) * f.tv_het.pair_stride + f.tv_het.off[0]);
+                dst[t * kHetChunk + (lane & 7)] = hstage[k * 2 * kHetChunk + lane];
+            }
+        }
+        hheld = 0;
+    };
+
+    for (uint64_t t = wave0; t < f.n_l2_dxy; t += n_waves) {
+        const uint64_t base = t * kTile2;
+        NodeDxy keep{0.0, 0u, 0u};
+        uint32_t hkeep = 0;  // lane c * 8 + u: packed counts of leaf u of genotype column c
+        if (base + kTile2 <= n) {
+            const double2 *__restrict__ q1 = reinterpret_cast<const double2 *>(f.p1 + base);
+            const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(f.p2 + base);
+            const int2 *__restrict__ m1 = reinterpret_cast<const int2 *>(f.n1 + base);
+            const int2 *__restrict__ m2 = reinterpret_cast<const int2 *>(f.n2 + base);
+            const uint4 *__restrict__ h0 = reinterpret_cast<const uint4 *>(f.g[0] + base);
+            const uint4 *__restrict__ h1 = reinterpret_cast<const uint4 *>(f.g[1] + base);
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += U) {
+                double2 x1[U], x2[U];
+                int2 k1[U], k2[U];
+                const int hb = j / U;  // batch index: batches 0..15 carry genotype load hb (column hb / 8, leaf hb % 8)
+                uint4 gw = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+                if (hb < 2 * kHetChunk) gw = load16_nt((hb < kHetChunk ? h0 : h1) + (hb & (kHetChunk - 1)) * kWave + lane);  // wave-uniform
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
+                    x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
+                    k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+                    k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    NodeDxy acc{0.0, 0u, 0u};
+                    dxy_acc(acc, dxy_site(x1[u].x, x2[u].x, k1[u].x, k2[u].x, f.minind));
+                    dxy_acc(acc, dxy_site(x1[u].y, x2[u].y, k1[u].y, k2[u].y, f.minind));
+                    acc = node_wave_sum(acc);
+                    if (lane == j + u) keep = acc;
+                }
+                if (hb < 2 * kHetChunk) {  // wave-uniform
+                    const uint32_t c = wave_sum(het_count_packed(gw));  // both fields <= 1024: no carry between them
+                    if (lane == hb) hkeep = c;
+                }
+            }
+        } else {  // the last, partial tile: site by site, sites beyond n count as nothing
+            for (int j = 0; j < kRadix; ++j) {
+                const uint64_t tile0 = base + (uint64_t)j * kLeafF64;
+                if (tile0 >= n) break;  // wave-uniform
+                NodeDxy acc{0.0, 0u, 0u};
+                for (int q = 0; q < 2; ++q) {
+                    const uint64_t i = tile0 + 2 * lane + q;
+                    if (i < n) dxy_acc(acc, dxy_site(f.p1[i], f.p2[i], f.n1[i], f.n2[i], f.minind));
+                }
+                acc = node_wave_sum(acc);
+                if (lane == j) keep = acc;
+            }
+            for (int hb = 0; hb < 2 * kHetChunk; ++hb) {
+                const int8_t *__restrict__ g = f.g[hb >> 3];
+                const uint64_t tile0 = base + (uint64_t)(hb & 7) * kLeafI8;
+                uint32_t nm = 0, nh = 0;
+                for (int q = 0; q < 16; ++q) {
+                    const uint64_t i = tile0 + (uint64_t)lane * 16 + q;
+                    if (i < n) {
+                        const int v = g[i];
+                        nm += v >= 0;
+                        nh += v == 1;
+                    }
+                }
+                const uint32_t c = wave_sum(nm | (nh << 16));
+                if (lane == hb) hkeep = c;
+            }
+        }
+        if (hheld == 0) hfirst = t;
+        if (lane < 2 * kHetChunk) hstage[hheld * 2 * kHetChunk + lane] = NodeHet{hkeep & 0xFFFFu, hkeep >> 16};
+        ++hheld;
+        const bool full = stage.held + 1 == kFstStage;
+        stage.put(t, keep);  // flushes the dxy rows when the stage is full
+        if (full) hflush();
+    }
+    stage.flush();
+    hflush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1153,10 +1274,14 @@ int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function
     const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>),
                             reinterpret_cast<const void *>(fst_build_kernel<kFstStage, 8, true>),
                             reinterpret_cast<const void *>(dxy_build_kernel<2>), reinterpret_cast<const void *>(dxy_build_kernel<4>),
-                            reinterpret_cast<const void *>(dxy_het_build_kernel<2>), reinterpret_cast<const void *>(dxy_het_build_kernel<4>),
                             reinterpret_cast<const void *>(ext_build_kernel<>), reinterpret_cast<const void *>(ext_build_kernel<kExtStage, 8, true>)};
     for (const void *k : staged)
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
+                              "hipFuncSetAttribute", err))
+            return rc;
+    const void *fused[] = {reinterpret_cast<const void *>(dxy_het_build_kernel<2>), reinterpret_cast<const void *>(dxy_het_build_kernel<4>)};
+    for (const void *k : fused)
+        if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDxyHetStageBytes),
                               "hipFuncSetAttribute", err))
             return rc;
     return PGT_OK;
@@ -1345,26 +1470,25 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
     char *base = static_cast<char *>(tree);
     const int lh = useful_levels(th, PGT_STAT_HET, hints.max_window);
     const TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, tot ? 0 : hints.max_window));
-    const TreeView tvh0 = make_view(th, base + td.bytes, th.bytes, lh);
-    const TreeView tvh1 = make_view(th, base + td.bytes + th.bytes, th.bytes, lh);
+    const TreeView tvh = make_view(th, base + td.bytes, th.bytes, lh);  // the two genotype trees, th.bytes apart
+    TreeView tvh1 = tvh;
+    tvh1.base += th.bytes;
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
-        const uint64_t n_items = het_items(n);
-        DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], n_items, tvd, {tvh0, tvh1}};
-        const uint64_t tiles = td.count[1] > n_items ? td.count[1] : n_items;
-        const dim3 grid(build_grid(tiles, kFstBuildBlocks), 3);
-        if (td.count[1] <= kFstSmallTiles)
-            hipLaunchKernelGGL(dxy_het_build_kernel<4>, grid, dim3(256), kFstStageBytes, s, f);
+        const uint64_t n_items = het_items(n);  // == td.count[1]: a dxy level-2 tile is one het work item
+        DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], tvd, tvh};
+        const dim3 grid(build_grid(td.count[1], kFstBuildBlocks));
+        if (td.count[1] <= kFstSmallTiles)  // 17 instead of 9 loads in flight per lane for short inputs (see fst_build_launch)
+            hipLaunchKernelGGL(dxy_het_build_kernel<4>, grid, dim3(256), kDxyHetStageBytes, s, f);
         else
-            hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kFstStageBytes, s, f);
+            hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kDxyHetStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
-        if (int rc = launch_upper<NodeHet>(th, tvh0, 1, s, err, 1, n_items * kHetChunk)) return rc;
-        if (int rc = launch_upper<NodeHet>(th, tvh1, 1, s, err, 1, n_items * kHetChunk)) return rc;
+        if (int rc = launch_upper<NodeHet>(th, tvh, 2, s, err, 1, n_items * kHetChunk)) return rc;  // both genotype trees per launch
     }
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0 || tot) {
-        DxyHetQueryArgs q{DxyTraits::Args{p1, p2, n1, n2, minind}, {g1, g2}, tvd, {tvh0, tvh1}, dxy_out, tot,
+        DxyHetQueryArgs q{DxyTraits::Args{p1, p2, n1, n2, minind}, {g1, g2}, tvd, {tvh, tvh1}, dxy_out, tot,
                           {het_out1, het_out2}};
         if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(dxy_het_query_slide_kernel, dim3(query_grid((n_win + group - 1) / group + 1), 3), dim3(256),

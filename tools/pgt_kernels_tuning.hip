@@ -4,7 +4,10 @@
 // the two launchers that have measured-and-rejected variants, and re-defines them with the build launch chosen
 // per call from environment variables (PGT_TUNE_BUILD_*, PGT_EXT_VARIANT[_NOW]); without those variables the
 // product launch runs.  The product file itself carries no preprocessor switch and no getenv.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #define launch_fst launch_fst_product
 #define launch_ext launch_ext_product
