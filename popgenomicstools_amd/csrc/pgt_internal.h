@@ -120,11 +120,21 @@ struct Hints {
     uint64_t max_window = 0;   // longest window in sites: tree levels with larger nodes are not built
     uint64_t window_step = 0;  // typical distance between consecutive window starts: selects the sliding query
 };
-// Windows per wave of the sliding query for a given step (0 or 1 = the one-wave-per-window query).
+// ---- query strategies, chosen from the hints alone (the same on every rank when the hints are) ----------------
+// step == 0 (unknown) or large: one wave per window.  step <= kSlideMaxStep: the sliding query (consecutive windows
+// share 128-site tiles: per-site scans).  kSlideMaxStep < step <= kGroupMaxStep and no window hint below two level-2
+// tiles: the group query (64 consecutive windows per wave share level-1 node scans and the interior).
+constexpr uint64_t kSlideMaxStep = 32;
+constexpr uint64_t kGroupMaxStep = 2048;
+// Windows per wave of the sliding query for a given step (0 or 1 = not the sliding query).
 inline uint32_t slide_group(uint64_t step) {
-    if (step == 0 || step > 32) return 1;
+    if (step == 0 || step > kSlideMaxStep) return 1;
     const uint64_t g = 128 / step + 1;
     return (uint32_t)(g > 64 ? 64 : g);
+}
+// leaf = sites per level-1 node of the statistic's tree (its level-2 tiles are 64 leaves)
+inline bool group_query(const Hints &h, uint64_t leaf) {
+    return h.window_step > kSlideMaxStep && h.window_step <= kGroupMaxStep && h.max_window >= 2 * leaf * kRadix;
 }
 
 // ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------

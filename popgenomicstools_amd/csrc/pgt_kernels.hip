@@ -1097,6 +1097,154 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// QUERY, group form (pgt_set_window_step in (kSlideMaxStep, kGroupMaxStep], windows of at least two level-2
+// tiles): one wave answers 64 CONSECUTIVE windows, one per lane — the regime of `-winsize 50000 -stepsize 100`,
+// where the per-window query pays four dependent round trips and ~3.3 KB of ragged reads for every window
+// (fstWindow.cpp:80-83,95-99 re-sums W sites and shifts W-S there).  A window [lo,hi) is cut at the leaf grid
+// (a1 = first leaf boundary >= lo, b1 = last <= hi) and at the level-2 grid (A, B likewise):
+//     [lo,a1) + [b1,hi)   ragged SITES, < one leaf each        -> wave-wide, one window at a time, 4 in flight
+//     [a1,A)              whole leaves inside lo's level-2 tile -> ONE suffix scan of that tile's 64 level-1
+//                                                                 nodes, shared by every window starting in it
+//     [A,B)               whole level-2 tiles                   -> ONE range query per distinct (A,B) of the group
+//     [B,b1)              whole leaves inside hi's level-2 tile -> ONE prefix scan, shared likewise
+// Consecutive windows start S sites apart, so the 64 starts of a group lie in 64 S / 8192 + 1 level-2 tiles
+// (2 at S = 100): the level-1 and level-2 reads of the per-window query (two ragged 1-KiB node loads and a
+// level-2 load per window, each a dependent round trip) shrink to a few loads per GROUP.  The pieces are
+// added in the fixed order edges, left leaves, interior, right leaves, and each piece is computed in an order
+// that depends on the window alone (fixed lane order of the scans; range_partial for the interior): rows are
+// bitwise independent of which windows share a wave, hence of the number of GPUs.  Windows the cut does not
+// fit (shorter than the level-2 grid allows: A > B) take the plain range query, one by one.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_lane) {  // wave-uniform src_lane
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+constexpr size_t kGroupLdsBytes = (size_t)4 * kRadix * 16;  // one 64-node table per wave
+
+template <class Tr>
+__device__ __forceinline__ void query_group_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
+                                                 const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
+                                                 typename Tr::Row *__restrict__ out, uint64_t n_sites, pgt_dxy_total *tot,
+                                                 int pair, char *lds) {
+    using Node = typename Tr::Node;
+    constexpr uint64_t kLeaf = (uint64_t)Tr::kLeaf, kTile2 = kLeaf * kRadix;
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const typename Tr::Cols c = Tr::cols(args, pair);
+    const char *tree = tv.base + (size_t)pair * tv.pair_stride;
+    const Node *__restrict__ l1 = reinterpret_cast<const Node *>(tree + tv.off[0]);
+    const uint64_t n_l1 = (n_sites + kLeaf - 1) / kLeaf;  // level-1 nodes the build wrote (the padding beyond is never read)
+    Node *table = reinterpret_cast<Node *>(lds) + (size_t)wib * kRadix;
+    const Node none = node_identity<Node>();
+    const uint64_t n_groups = (n_win + kWave - 1) / kWave;
+    const uint64_t n_tasks = n_groups + (tot ? 1 : 0);
+
+    for (uint64_t task = wave0; task < n_tasks; task += n_waves) {
+        if (task == n_groups) {  // the genome-wide total (dxy)
+            const Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, 0, n_sites, lane, n_sites));
+            if (lane == 0) Tr::store_total(tot, acc);
+            continue;
+        }
+        const uint64_t w = task * kWave + (uint64_t)lane;
+        const bool active = w < n_win;
+        pgt_win wd;
+        wd.lo = wd.hi = 0; wd.flags = PGT_WIN_COORDS; wd.start = wd.end = 0; wd.label_run = 0;
+        if (active) wd = win[w];
+        const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
+        const uint64_t lo = wd.lo < hi ? wd.lo : hi;
+        const uint64_t a1 = (lo + kLeaf - 1) / kLeaf * kLeaf, b1 = hi / kLeaf * kLeaf;
+        const uint64_t A = (lo + kTile2 - 1) / kTile2 * kTile2, B = hi / kTile2 * kTile2;
+        const bool fast = active && hi > lo && A <= B;  // then lo <= a1 <= A <= B <= b1 <= hi
+        Node sum = none;
+
+        // (1) the ragged sites at both ends: wave-wide per window, the loads of four windows in flight together
+        for (unsigned long long m = __ballot(fast); m != 0;) {
+            Node acc[4];
+            int src[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                src[u] = m != 0 ? __ffsll((long long)m) - 1 : -1;
+                if (m != 0) m &= m - 1;
+                acc[u] = none;
+                if (src[u] >= 0)  // wave-uniform
+                    ragged_pair<Tr>(acc[u], c, tree, tv, 0, readlane_u64(lo, src[u]), readlane_u64(a1, src[u]),
+                                    readlane_u64(b1, src[u]), readlane_u64(hi, src[u]), lane, n_sites);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (src[u] >= 0) {
+                    const Node e = node_wave_sum(acc[u]);
+                    if (lane == src[u]) sum = e;
+                }
+        }
+        // (2) whole leaves between a1 and A: a suffix scan of the 64 level-1 nodes of lo's level-2 tile
+        {
+            bool pend = fast && a1 < A;
+            const uint64_t myT = lo / kTile2;
+            for (unsigned long long m = __ballot(pend); m != 0; m = __ballot(pend)) {
+                const uint64_t T = readlane_u64(myT, __ffsll((long long)m) - 1);
+                const uint64_t i = T * kRadix + (uint64_t)lane;
+                const Node v = i < n_l1 ? l1[i] : none;
+                Node sfx = lane_scan_exclusive<Node, true>(v, lane);  // the lanes above, in a fixed order
+                node_add(sfx, v);
+                table[lane] = sfx;  // the wave's own LDS row: operations of one wave complete in order
+                if (pend && myT == T) {
+                    node_add(sum, table[(a1 - T * kTile2) / kLeaf]);
+                    pend = false;
+                }
+            }
+        }
+        // (3) whole level-2 tiles: one range query per distinct (A,B)
+        {
+            bool pend = fast && A < B;
+            for (unsigned long long m = __ballot(pend); m != 0; m = __ballot(pend)) {
+                const int L = __ffsll((long long)m) - 1;
+                const uint64_t Au = readlane_u64(A, L), Bu = readlane_u64(B, L);
+                const Node mid = node_wave_sum(range_partial<Tr>(c, tree, tv, Au, Bu, lane, n_sites));
+                if (pend && A == Au && B == Bu) {
+                    node_add(sum, mid);
+                    pend = false;
+                }
+            }
+        }
+        // (4) whole leaves between B and b1: a prefix scan of the level-1 nodes of hi's level-2 tile
+        {
+            bool pend = fast && B < b1;
+            const uint64_t myT = hi / kTile2;  // B == myT * kTile2
+            for (unsigned long long m = __ballot(pend); m != 0; m = __ballot(pend)) {
+                const uint64_t T = readlane_u64(myT, __ffsll((long long)m) - 1);
+                const uint64_t i = T * kRadix + (uint64_t)lane;
+                const Node v = i < n_l1 ? l1[i] : none;
+                table[lane] = lane_scan_exclusive<Node, false>(v, lane);  // the lanes below: nodes 0 .. lane-1
+                if (pend && myT == T) {
+                    node_add(sum, table[(b1 - B) / kLeaf]);  // 1 .. 63
+                    pend = false;
+                }
+            }
+        }
+        uint32_t start = wd.start, end = wd.end;
+        if (active && !(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
+            start = hi > lo ? pos[lo] : 0u;
+            end = hi > lo ? pos[hi - 1] : 0u;
+        }
+        typename Tr::Row *row = out + (uint64_t)pair * n_win + w;
+        if (fast) Tr::finish(row, sum, start, end, lo, hi, c, pos);
+        // windows the cut does not fit (or empty ones): the plain range query, whose order depends on the window alone too
+        bool slow = active && !fast;
+        for (unsigned long long m = __ballot(slow); m != 0; m = __ballot(slow)) {
+            const int L = __ffsll((long long)m) - 1;
+            const Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, readlane_u64(lo, L), readlane_u64(hi, L), lane, n_sites));
+            if (lane == L) {
+                Tr::finish(row, acc, start, end, lo, hi, c, pos);
+                slow = false;
+            }
+        }
+    }
+}
+
 template <class Tr>
 __global__ __launch_bounds__(256) void query_kernel(typename Tr::Args args, const uint32_t *pos, TreeView tv,
                                                     const pgt_win *win, uint64_t n_win, typename Tr::Row *out,
@@ -1141,6 +1289,29 @@ __global__ __launch_bounds__(256) void dxy_het_query_slide_kernel(DxyHetQueryArg
     }
 }
 constexpr size_t kSlideLdsBytes = (size_t)4 * 4 * kSlideTile * 16;  // 4 waves x 4 tiles x 128 nodes of <= 16 B
+
+template <class Tr>
+__global__ __launch_bounds__(256) void query_group_kernel(typename Tr::Args args, const uint32_t *pos, TreeView tv,
+                                                          const pgt_win *win, uint64_t n_win, typename Tr::Row *out,
+                                                          uint64_t n_sites, pgt_dxy_total *tot) {
+    extern __shared__ __attribute__((aligned(16))) char lds_group[];
+    query_group_body<Tr>(args, pos, tv, win, n_win, out, n_sites, tot, (int)blockIdx.y, lds_group);
+}
+// config 3 with a step in the group range: the dxy table in groups; the genotype tables in groups only when the windows
+// are long enough for the int8 tree's level-2 grid (65536 sites), else per window
+__global__ __launch_bounds__(256) void dxy_het_query_group_kernel(DxyHetQueryArgs f, const uint32_t *pos, const pgt_win *win,
+                                                                  uint64_t n_win, uint64_t n_sites, int het_in_groups) {
+    extern __shared__ __attribute__((aligned(16))) char lds_group[];
+    if (blockIdx.y == 0) {
+        query_group_body<DxyTraits>(f.dxy, pos, f.tv_dxy, win, n_win, f.dxy_out, n_sites, f.tot, 0, lds_group);
+    } else {
+        const int k = blockIdx.y - 1;
+        if (het_in_groups)
+            query_group_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0, lds_group);
+        else
+            query_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0);
+    }
+}
 
 inline int hip_fail(hipError_t e, const char *what, std::string *err) {
     if (e == hipSuccess) return PGT_OK;
@@ -1331,6 +1502,10 @@ int launch_fst_with(BuildFn build, const uint32_t *pos, const double *const *a, 
                 hipLaunchKernelGGL(query_slide_kernel<FstTraits>, dim3(query_grid((n_win + group - 1) / group), np), dim3(256),
                                    kSlideLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
                                    (pgt_dxy_total *)nullptr, group);
+            else if (group_query(hints, kLeafF64))
+                hipLaunchKernelGGL(query_group_kernel<FstTraits>, dim3(query_grid((n_win + kWave - 1) / kWave), np), dim3(256),
+                                   kGroupLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
+                                   (pgt_dxy_total *)nullptr);
             else
                 hipLaunchKernelGGL(query_kernel<FstTraits>, dim3(query_grid(n_win), np), dim3(256), 0, s, args, pos,
                                    tv, win, n_win, out + (uint64_t)p0 * n_win, n, (pgt_dxy_total *)nullptr);
@@ -1373,6 +1548,9 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
         if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(query_slide_kernel<HetTraits>, dim3(query_grid((n_win + group - 1) / group)), dim3(256),
                                kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr, group);
+        else if (group_query(hints, kLeafI8))
+            hipLaunchKernelGGL(query_group_kernel<HetTraits>, dim3(query_grid((n_win + kWave - 1) / kWave)), dim3(256),
+                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr);
         else
             hipLaunchKernelGGL(query_kernel<HetTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win,
                                n_win, out, n, (pgt_dxy_total *)nullptr);
@@ -1405,6 +1583,9 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
         if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(query_slide_kernel<DxyTraits>, dim3(query_grid((n_win + group - 1) / group + 1)), dim3(256),
                                kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, tot, group);
+        else if (group_query(hints, kLeafF64))
+            hipLaunchKernelGGL(query_group_kernel<DxyTraits>, dim3(query_grid((n_win + kWave - 1) / kWave + 1)), dim3(256),
+                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, tot);
         else
             hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
                                win, n_win, out, n, tot);
@@ -1493,7 +1674,12 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(dxy_het_query_slide_kernel, dim3(query_grid((n_win + group - 1) / group + 1), 3), dim3(256),
                                kSlideLdsBytes, s, q, pos, win, n_win, n, group);
-        else
+        else if (group_query(hints, kLeafF64)) {
+            const int het_groups = group_query(hints, kLeafI8) ? 1 : 0;
+            const uint64_t items = het_groups ? (n_win + kWave - 1) / kWave + 1 : n_win + 1;
+            hipLaunchKernelGGL(dxy_het_query_group_kernel, dim3(query_grid(items), 3), dim3(256), kGroupLdsBytes, s, q, pos, win,
+                               n_win, n, het_groups);
+        } else
             hipLaunchKernelGGL(dxy_het_query_kernel, dim3(query_grid(n_win + 1), 3), dim3(256), 0, s, q, pos, win, n_win, n);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_query_kernel", err)) return rc;
     }

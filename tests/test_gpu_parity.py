@@ -1091,6 +1091,26 @@ def test_sliding_query_vs_oracle(pgt, ctx, oracle, W, S):
         check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, 5, 1, 0)
 
 
+@pytest.mark.parametrize("W,S,n", [(50_000, 33, 250_000), (50_000, 64, 250_000), (50_000, 100, 300_000), (50_000, 500, 400_000),
+                                   (50_000, 2000, 600_000), (50_000, 2048, 600_000), (16_384, 100, 120_000), (16_383, 100, 120_000),
+                                   (20_000, 777, 200_000), (140_000, 1000, 900_000)])
+def test_group_query_vs_oracle(pgt, ctx, oracle, W, S, n):
+    """32 < S <= 2048 (`-winsize 50000 -stepsize 100`: fstWindow.cpp:80-83,95-99 re-sums W sites per window there): the host
+    API derives the step hint from the table and takes the GROUP query — 64 consecutive windows per wave, level-1 node scans
+    and the interior shared.  Every statistic against the oracle (ints exact, floats 1e-9) on ragged chromosome layouts:
+    short chromosomes and W = 16383 exercise the per-window fallback inside a group, W = 140000 puts the int8 tree
+    (65536-site level-2 tiles) on the group path too."""
+    rng = np.random.default_rng(W * 7 + S)
+    for n_chr in (1, 4, 23):
+        chr_ids, pos = synth.chromosomes(rng, n, n_chr, equal=False)
+        a, b = synth.fst_columns(rng, n)
+        check_fst(pgt, ctx, oracle, chr_ids, pos, a, b, W, S)
+        g = synth.het_column(rng, n)
+        check_het(pgt, ctx, oracle, chr_ids, pos, g, W, S)
+        p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+        check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, 5, 1, 0)
+
+
 def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt, ctx):
     """Device API: with the step hint (sliding) and without (one wave per window) the integer columns
     are identical and the sums agree to 1e-9; het rows are bitwise equal (integer sums); and the sliding
@@ -1105,9 +1125,10 @@ def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt
     g = synth.het_column(rng, n).astype(np.int8)
     t = lambda x: torch.from_numpy(x).to(dev)
     tp, ta, tb, tg = t(pos.view(np.int32)), t(a), t(b), t(g)
-    for W, S in ((50_000, 1), (10_000, 3), (777, 16)):
+    for W, S in ((50_000, 1), (10_000, 3), (777, 16), (50_000, 100), (30_000, 700), (140_000, 1500), (9_000, 50)):  # the last four: group query
         win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
         wt = windows_to_device(win, dev)
+        ctx.set_max_window(W)
         ctx.set_window_step(0)
         std, _ = ctx.fst_reduce_dev(tp, ta, tb, wt)
         hstd, _ = ctx.het_reduce_dev(tp, tg, wt)
@@ -1131,6 +1152,7 @@ def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt
                 parts.append(rows_from_device(o, FST_ROW_DTYPE))
             assert np.concatenate(parts).tobytes() == r1.tobytes(), (W, S, world)
     ctx.set_window_step(0)
+    ctx.set_max_window(0)
 
 
 def test_sliding_query_with_batched_pairs_and_fused_statistics(pgt, ctx):
@@ -1139,35 +1161,38 @@ def test_sliding_query_with_batched_pairs_and_fused_statistics(pgt, ctx):
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(909)
-    n, W, S, n_pairs = 200_000, 3_000, 1, 3
+    n, n_pairs = 200_000, 3
     chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
     cols = [synth.fst_columns(rng, n) for _ in range(n_pairs)]
-    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
-    wt = windows_to_device(win, dev)
     t = lambda x: torch.from_numpy(x).to(dev)
     tp = t(pos.view(np.int32))
     ta, tb = [t(c[0]) for c in cols], [t(c[1]) for c in cols]
-    ctx.set_window_step(S)
-    try:
-        out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, wt)
-        torch.cuda.synchronize()
-        rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
-        for p in range(n_pairs):
-            single, _ = ctx.fst_reduce_dev(tp, ta[p], tb[p], wt)
-            torch.cuda.synchronize()
-            assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
-        p1, p2, n1, n2 = synth.dxy_columns(rng, n)
-        g1 = synth.het_column(rng, n).astype(np.int8)
-        g2 = synth.het_column(rng, n).astype(np.int8)
-        d, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), t(g1), t(g2), 5, wt)
-        ds, tots, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wt)
-        hs, _ = ctx.het_reduce_dev(tp, t(g2), wt)
-        torch.cuda.synchronize()
-        assert rows_from_device(d, DXY_ROW_DTYPE).tobytes() == rows_from_device(ds, DXY_ROW_DTYPE).tobytes()
-        assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tots, DXY_TOTAL_DTYPE).tobytes()
-        assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
-    finally:
+    for W, S in ((3_000, 1), (20_000, 100), (140_000, 300)):  # sliding; group (dxy in groups, het per window); group for both trees
+      win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+      wt = windows_to_device(win, dev)
+      ctx.set_max_window(W)
+      ctx.set_window_step(S)
+      try:
+          out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, wt)
+          torch.cuda.synchronize()
+          rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+          for p in range(n_pairs):
+              single, _ = ctx.fst_reduce_dev(tp, ta[p], tb[p], wt)
+              torch.cuda.synchronize()
+              assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
+          p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+          g1 = synth.het_column(rng, n).astype(np.int8)
+          g2 = synth.het_column(rng, n).astype(np.int8)
+          d, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), t(g1), t(g2), 5, wt)
+          ds, tots, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wt)
+          hs, _ = ctx.het_reduce_dev(tp, t(g2), wt)
+          torch.cuda.synchronize()
+          assert rows_from_device(d, DXY_ROW_DTYPE).tobytes() == rows_from_device(ds, DXY_ROW_DTYPE).tobytes()
+          assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tots, DXY_TOTAL_DTYPE).tobytes()
+          assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
+      finally:
         ctx.set_window_step(0)
+        ctx.set_max_window(0)
 
 
 def test_sharded_dxy_scan_single_process(pgt, ctx):

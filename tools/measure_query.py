@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Query-kernel time for S << W on one MI355X: fstWindow, 10^8 sites, W = 50000, S in {1, 8, 32, 100, 10000}, with the
-per-window query (step hint 0) and with the sliding query (step hint S; it only switches for S <= 32).  Markdown on stdout.
+"""Query-kernel time for S << W on one MI355X: fstWindow, 10^8 sites, W = 50000, S in {1, 8, 32, 64, 100, 500, 1000, 2048, 10000},
+with the per-window query (step hint 0) and with the strategy the step hint S selects (S <= 32 sliding, 32 < S <= 2048
+group, above that the hint changes nothing).  Markdown on stdout.
 usage: measure_query.py [sites [steps,comma,separated [winsize]]]"""
 import os
 import sys
@@ -18,7 +19,7 @@ from synth_genome import SynthGenome  # noqa: E402
 
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
-    steps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 32, 100, 10_000]
+    steps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 32, 64, 100, 500, 1000, 2048, 10_000]
     dev = torch.device("cuda", 0)
     g = SynthGenome(12345, n, 20)
     pos, a, b = g.fst_columns_t(0, n, dev)
@@ -37,7 +38,7 @@ def main():
         del win_h
         out = [torch.empty(nw * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
         res = {}
-        for k, (name, hint) in enumerate((("per-window", 0), ("sliding" if S <= 32 else "per-window (hint ignored: S > 32)", S))):
+        for k, (name, hint) in enumerate((("per-window", 0), ("sliding" if S <= 32 else ("group" if S <= 2048 else "per-window (hint ignored: S > 2048)"), S))):
             ctx.set_window_step(hint)
             q, bms = [], []
             for r in range(4):
