@@ -241,26 +241,33 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     out["ihs_extreme_1e8"] = dict(r, config="SURVEY 8(f3): ihsWindow-style extreme-score scan, 1e8 sites, 100 kb windows",
                                   kernel="ext_build_kernel")
     del score
-    # S << W (fstWindow W=50000, S=1) on 10^7 sites: the sliding query against the per-window query
+    # S << W (fstWindow W=50000, S=1 and S=100) on 10^7 sites: the query strategies against one wave per window
     n7 = 10_000_000
-    win1_h = pgt.build_windows_sites(np.array([n7], dtype=np.uint64), W, 1)
-    win1 = windows_to_device(win1_h, dev)
-    rows1 = torch.empty(win1_h.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    ctx.set_max_window(W)
     q = {}
-    for name, hint in (("per_window", 0), ("sliding", 1)):
-        ctx.set_window_step(hint)
-        ctx.set_profiling(True)
-        t = []
-        for _ in range(4):
-            ctx.fst_reduce_dev(pos[:n7], a[:n7], b[:n7], win1, out=rows1, tree=tree_pool)
-            t.append(ctx.last_kernel_ms()[1])
-        ctx.set_profiling(False)
-        q[name] = float(np.median(t[1:]))
+    for S_ in (1, 100):
+        win1_h = pgt.build_windows_sites(np.array([n7], dtype=np.uint64), W, S_)
+        win1 = windows_to_device(win1_h, dev)
+        rows1 = torch.empty(win1_h.size * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        # (name, step hint, longest-window hint): an unknown longest window (0) rules the group query out -> the sliding one
+        for name, hint, mw in (("per_window", 0, W), ("sliding", S_, 0), ("group", S_, W)):
+            if name == "sliding" and S_ > 32:
+                continue
+            ctx.set_max_window(mw)
+            ctx.set_window_step(hint)
+            ctx.set_profiling(True)
+            t = []
+            for _ in range(4):
+                ctx.fst_reduce_dev(pos[:n7], a[:n7], b[:n7], win1, out=rows1, tree=tree_pool)
+                t.append(ctx.last_kernel_ms()[1])
+            ctx.set_profiling(False)
+            q[f"S{S_}_{name}"] = float(np.median(t[1:]))
+        q[f"S{S_}_windows"] = int(win1_h.size)
+        del win1, rows1
     ctx.set_window_step(0)
-    out["fst_1e7_step1_query"] = {"config": "fstWindow 1e7 sites, W=50000, S=1 (9.95e6 windows): query kernel only",
-                                  "query_ms_per_window_strategy": q["per_window"], "query_ms_sliding_strategy": q["sliding"],
-                                  "windows": int(win1_h.size)}
+    ctx.set_max_window(W)
+    out["fst_1e7_small_step_query"] = {"config": "fstWindow 1e7 sites, W=50000, S=1 (9.95e6 windows) and S=100 (99501 windows): query kernel only, ms; "
+                                                 "the product takes the group query for both (pgt_set_window_step <= 512, windows >= 16384 sites)",
+                                       **q}
     return out
 
 

@@ -206,14 +206,20 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
 /* Longest window (in sites) the following *_dev calls will be asked for; 0 (the default) = unknown.
  * Tree levels whose nodes are larger than this are not built (a query never touches them).  The
  * hint only affects speed: a longer window is still answered correctly from the levels that
- * exist.  The host-buffer entry points derive it from the table themselves. */
+ * exist.  The host-buffer / *_cols entry points derive a hint from the table only while it is unknown (0): a caller
+ * that reduces SLICES of one table on several GPUs sets both hints from the whole table (W, S), so that every
+ * slice — and the single-GPU run — takes the same query strategy: rows are bitwise independent of the number of
+ * GPUs only under identical hints (the strategies add in different orders). */
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
 /* Typical distance, in sites, between the starts of consecutive windows of the following *_dev calls
  * (the tools' step size S); 0 (the default) = unknown.  With a step of at most 32 sites the queries
  * use the SLIDING strategy: one wave answers a group of consecutive windows from one suffix scan of
  * the sites around their starts, one prefix scan around their ends and ONE tree query for the
  * interior they share, instead of one tree query per window — the regime of `-winsize W -stepsize 1`
- * (fstWindow.cpp:80-83,95-99: the reference re-sums W sites and shifts W-S per window there).  Speed
+ * (fstWindow.cpp:80-83,95-99: the reference re-sums W sites and shifts W-S per window there); with a step
+ * of 33 .. 512 sites (and windows of at least two level-2 tiles: 16384 sites for the f64 trees) the GROUP
+ * strategy: 64 consecutive windows per wave share the scans of the 128-site tiles under their ends, the scans
+ * of the level-1 nodes beside them and the interior query (`-winsize 50000 -stepsize 100`).  Speed
  * only: any table is answered correctly whatever the hint (groups that do not slide fall back to the
  * per-window query); sums are taken in a different order, so the last bits of a float may differ
  * between the two strategies.  The host-buffer entry points derive the hint from the table. */
@@ -267,6 +273,14 @@ int pgt_rowbuf_read(pgt_ctx *ctx, void *host_dst, const void *dev_src, size_t by
  * fills its slice of the shared buffer, the owner reads it back (pgt_rowbuf_read) and compares. */
 int pgt_rowbuf_fill(pgt_ctx *ctx, void *dev_ptr, size_t bytes, uint64_t seed, void *stream);
 
+/* ---- plain device buffers (for callers without a HIP binding of their own: the C++ hosts' multi-GPU path) --------
+ * One process may hold one pgt_ctx per GPU (one thread each).  pgt_dev_copy moves bytes between buffers of two
+ * contexts — the same device, or two devices (peer copy where the link allows it, staged by the runtime otherwise);
+ * it is synchronous and may be called from the thread of either context. */
+int pgt_dev_alloc(pgt_ctx *ctx, size_t bytes, void **dev_ptr);
+int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr);
+int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src, size_t bytes);
+
 /* ---- device-side text ingest ------------------------------------------------ */
 /* Replaces the per-line text parse of the reference's streaming loops (fstWindow.cpp:123-146 `chr pos a b`,
  * hetWindow.cpp:121-144 `chr pos genotype`, dxyWindow.cpp:141-153,399-403 `chr pos major minor ref freq nInd`):
@@ -309,6 +323,9 @@ int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1,
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
 uint64_t pgt_ingest_rows(const pgt_ingest *ing);
+/* 1 when the data ended at a blank line BEFORE the last line of `text` (the tools stop reading there, fstWindow.cpp:125):
+ * a caller that hands consecutive pieces of one file to several GPUs must drop the pieces behind such a one. */
+int pgt_ingest_blank_before_end(const pgt_ingest *ing);
 int64_t pgt_ingest_bad_line(const pgt_ingest *ing);
 void *pgt_ingest_column(const pgt_ingest *ing, int token);
 size_t pgt_ingest_runs(const pgt_ingest *ing, const uint64_t **run_len, const uint64_t **name_off, const uint32_t **name_len);

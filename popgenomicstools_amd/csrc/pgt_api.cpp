@@ -68,7 +68,7 @@ struct HintScope {
         uint64_t m = 1;
         for (uint64_t i = 0; i < n_win; ++i)
             if (win[i].hi >= win[i].lo && win[i].hi - win[i].lo > m) m = win[i].hi - win[i].lo;
-        c->hints.max_window = m;
+        if (saved.max_window == 0) c->hints.max_window = m;  // an explicit hint (the caller knows the whole table) stays
         // typical step = median distance between consecutive window starts (a sample from the middle of the
         // table: chromosome boundaries and the Q1 carry make a few distances irregular)
         std::vector<uint64_t> d;
@@ -80,7 +80,7 @@ struct HintScope {
             std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
             step = d[d.size() / 2];
         }
-        c->hints.window_step = step;
+        if (saved.window_step == 0) c->hints.window_step = step;
     }
     ~HintScope() { ctx->hints = saved; }
 };
@@ -431,6 +431,30 @@ int pgt_rowbuf_fill(pgt_ctx *ctx, void *dev_ptr, size_t bytes, uint64_t seed, vo
     if (!dev_ptr || (bytes & 7u) || (reinterpret_cast<uintptr_t>(dev_ptr) & 7u))
         return ctx_fail(ctx, PGT_EARG, "pgt_rowbuf_fill: NULL or misaligned argument");
     return launch_fill_pattern(static_cast<uint64_t *>(dev_ptr), bytes / 8, seed, stream, &ctx->error);
+}
+
+/* ---------------- plain device buffers ---------------- */
+
+int pgt_dev_alloc(pgt_ctx *ctx, size_t bytes, void **dev_ptr) {
+    PGT_USE_DEVICE(ctx);
+    if (!dev_ptr) return ctx_fail(ctx, PGT_EARG, "pgt_dev_alloc: NULL argument");
+    return hip_check(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16), "pgt_dev_alloc: hipMalloc");
+}
+
+int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr) {
+    PGT_USE_DEVICE(ctx);
+    if (!dev_ptr) return PGT_OK;
+    return hip_check(ctx, hipFree(dev_ptr), "pgt_dev_free: hipFree");
+}
+
+int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src, size_t bytes) {
+    PGT_USE_DEVICE(dst_ctx);
+    if (!src_ctx) return ctx_fail(dst_ctx, PGT_EARG, "pgt_dev_copy: NULL source context");
+    if (bytes == 0) return PGT_OK;
+    if (!dst || !src) return ctx_fail(dst_ctx, PGT_EARG, "pgt_dev_copy: NULL argument");
+    if (src_ctx->device == dst_ctx->device)
+        return hip_check(dst_ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice), "pgt_dev_copy: hipMemcpy");
+    return hip_check(dst_ctx, hipMemcpyPeer(dst, dst_ctx->device, src, src_ctx->device, bytes), "pgt_dev_copy: hipMemcpyPeer");
 }
 
 /* ---------------- host-buffer entry points ---------------- */

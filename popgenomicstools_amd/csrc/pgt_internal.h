@@ -121,11 +121,13 @@ struct Hints {
     uint64_t window_step = 0;  // typical distance between consecutive window starts: selects the sliding query
 };
 // ---- query strategies, chosen from the hints alone (the same on every rank when the hints are) ----------------
-// step == 0 (unknown) or large: one wave per window.  step <= kSlideMaxStep: the sliding query (consecutive windows
-// share 128-site tiles: per-site scans).  kSlideMaxStep < step <= kGroupMaxStep and no window hint below two level-2
-// tiles: the group query (64 consecutive windows per wave share level-1 node scans and the interior).
+// step == 0 (unknown) or large: one wave per window.  0 < step <= kGroupMaxStep and windows of at least two level-2
+// tiles (max-window hint): the GROUP query (64 consecutive windows per wave share tile scans, level-1 node scans and the
+// interior) — it beats the sliding query at every step it applies to (10^8 sites, W = 50000: S = 1 2.85 against 4.10 ms,
+// S = 8 0.65 against 1.80, S = 32 0.60 against 1.55; profiles/r03/measure_query_1e8_strategies.md).  Shorter windows
+// with step <= kSlideMaxStep: the sliding query (per-site scans of 128-site tiles; it needs only 256-site windows).
 constexpr uint64_t kSlideMaxStep = 32;
-constexpr uint64_t kGroupMaxStep = 2048;
+constexpr uint64_t kGroupMaxStep = 512;  // above, a group's 64 starts span too many level-2 tiles and there are too few groups to fill the chip
 // Windows per wave of the sliding query for a given step (0 or 1 = not the sliding query).
 inline uint32_t slide_group(uint64_t step) {
     if (step == 0 || step > kSlideMaxStep) return 1;
@@ -134,7 +136,13 @@ inline uint32_t slide_group(uint64_t step) {
 }
 // leaf = sites per level-1 node of the statistic's tree (its level-2 tiles are 64 leaves)
 inline bool group_query(const Hints &h, uint64_t leaf) {
-    return h.window_step > kSlideMaxStep && h.window_step <= kGroupMaxStep && h.max_window >= 2 * leaf * kRadix;
+    return h.window_step > 0 && h.window_step <= kGroupMaxStep && h.max_window >= 2 * leaf * kRadix;
+}
+// the group query's ragged ends: shared 128-site tile scans up to this step, per window above (see query_group_body)
+inline int group_edge_scans(const Hints &h) { return h.window_step <= 64 ? 1 : 0; }
+// Windows per wave of the group query: 64 when that still gives the chip ~8000 waves, else fewer (rows do not depend on it)
+inline uint32_t group_size(uint64_t n_win) {
+    return n_win >= 64ull * 8192 ? 64u : (n_win >= 32ull * 8192 ? 32u : 16u);
 }
 
 // ---- launchers implemented in pgt_kernels.hip (stream = hipStream_t as void*) ----------

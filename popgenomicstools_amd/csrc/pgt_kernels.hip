@@ -520,6 +520,12 @@ struct FstTraits {
     struct Cols { const double *a, *b; };
     static __device__ __forceinline__ Cols cols(const Args &g, int pair) { return {g.cols.a[pair], g.cols.b[pair]}; }
     static __device__ __forceinline__ Node leaf(const Cols &c, uint64_t i) { return {c.a[i], c.b[i]}; }
+    // sites i0 (even) and i0 + 1 by one 16-byte load per column (the columns are 16-byte aligned)
+    static __device__ __forceinline__ void leaf_pair(const Cols &c, uint64_t i0, Node &v0, Node &v1) {
+        const double2 a2 = *reinterpret_cast<const double2 *>(c.a + i0), b2 = *reinterpret_cast<const double2 *>(c.b + i0);
+        v0 = {a2.x, b2.x};
+        v1 = {a2.y, b2.y};
+    }
     static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
                                                      uint64_t) {
         for (uint64_t i = from + lane; i < to; i += kWave) node_add(acc, leaf(c, i));
@@ -605,6 +611,14 @@ struct DxyTraits {
         Node v{0.0, 0u, 0u};
         dxy_acc(v, dxy_site(c.p1[i], c.p2[i], c.n1[i], c.n2[i], c.minind));
         return v;
+    }
+    static __device__ __forceinline__ void leaf_pair(const Cols &c, uint64_t i0, Node &v0, Node &v1) {  // i0 even
+        const double2 x1 = *reinterpret_cast<const double2 *>(c.p1 + i0), x2 = *reinterpret_cast<const double2 *>(c.p2 + i0);
+        const int2 k1 = *reinterpret_cast<const int2 *>(c.n1 + i0), k2 = *reinterpret_cast<const int2 *>(c.n2 + i0);
+        v0 = Node{0.0, 0u, 0u};
+        v1 = Node{0.0, 0u, 0u};
+        dxy_acc(v0, dxy_site(x1.x, x2.x, k1.x, k2.x, c.minind));
+        dxy_acc(v1, dxy_site(x1.y, x2.y, k1.y, k2.y, c.minind));
     }
     static __device__ __forceinline__ void sum_sites(Node &acc, const Cols &c, uint64_t from, uint64_t to, int lane,
                                                      uint64_t) {
@@ -1121,13 +1135,13 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_lane) {  //
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
     return ((uint64_t)hi << 32) | lo;
 }
-constexpr size_t kGroupLdsBytes = (size_t)4 * kRadix * 16;  // one 64-node table per wave
+constexpr size_t kGroupLdsBytes = (size_t)4 * 2 * kLeafF64 * 16;  // per wave: two 128-entry scan tables (also used, 64 entries each, for the node scans)
 
 template <class Tr>
 __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
                                                  const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
                                                  typename Tr::Row *__restrict__ out, uint64_t n_sites, pgt_dxy_total *tot,
-                                                 int pair, char *lds) {
+                                                 int pair, uint32_t group, bool edge_scans, char *lds) {
     using Node = typename Tr::Node;
     constexpr uint64_t kLeaf = (uint64_t)Tr::kLeaf, kTile2 = kLeaf * kRadix;
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -1137,9 +1151,9 @@ __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, 
     const char *tree = tv.base + (size_t)pair * tv.pair_stride;
     const Node *__restrict__ l1 = reinterpret_cast<const Node *>(tree + tv.off[0]);
     const uint64_t n_l1 = (n_sites + kLeaf - 1) / kLeaf;  // level-1 nodes the build wrote (the padding beyond is never read)
-    Node *table = reinterpret_cast<Node *>(lds) + (size_t)wib * kRadix;
+    Node *table = reinterpret_cast<Node *>(lds) + (size_t)wib * 2 * kLeafF64;  // [2][128]
     const Node none = node_identity<Node>();
-    const uint64_t n_groups = (n_win + kWave - 1) / kWave;
+    const uint64_t n_groups = (n_win + group - 1) / group;
     const uint64_t n_tasks = n_groups + (tot ? 1 : 0);
 
     for (uint64_t task = wave0; task < n_tasks; task += n_waves) {
@@ -1148,8 +1162,8 @@ __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, 
             if (lane == 0) Tr::store_total(tot, acc);
             continue;
         }
-        const uint64_t w = task * kWave + (uint64_t)lane;
-        const bool active = w < n_win;
+        const uint64_t w = task * group + (uint64_t)lane;
+        const bool active = (uint32_t)lane < group && w < n_win;
         pgt_win wd;
         wd.lo = wd.hi = 0; wd.flags = PGT_WIN_COORDS; wd.start = wd.end = 0; wd.label_run = 0;
         if (active) wd = win[w];
@@ -1160,25 +1174,83 @@ __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, 
         const bool fast = active && hi > lo && A <= B;  // then lo <= a1 <= A <= B <= b1 <= hi
         Node sum = none;
 
-        // (1) the ragged sites at both ends: wave-wide per window, the loads of four windows in flight together
-        for (unsigned long long m = __ballot(fast); m != 0;) {
-            Node acc[4];
-            int src[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                src[u] = m != 0 ? __ffsll((long long)m) - 1 : -1;
-                if (m != 0) m &= m - 1;
-                acc[u] = none;
-                if (src[u] >= 0)  // wave-uniform
-                    ragged_pair<Tr>(acc[u], c, tree, tv, 0, readlane_u64(lo, src[u]), readlane_u64(a1, src[u]),
-                                    readlane_u64(b1, src[u]), readlane_u64(hi, src[u]), lane, n_sites);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (src[u] >= 0) {
-                    const Node e = node_wave_sum(acc[u]);
-                    if (lane == src[u]) sum = e;
+        // (1) the ragged sites at both ends.  edge_scans (steps up to 64 sites, f64 trees; wave-uniform, fixed by the hint):
+        // [lo,a1) is a suffix of lo's 128-site leaf tile, [b1,hi) a prefix of hi's: ONE scan per DISTINCT tile (16-byte loads,
+        // fixed lane order), shared by every window of the group that starts (ends) in it — at S = 32 the 64 starts lie in
+        // 17 tiles, at S = 1 in one or two.  A left and a right tile are loaded together per iteration.  From 64 sites on
+        // nearly every window has tiles of its own and the scan costs more than it shares (S = 100, 10^6 windows: 0.535 ms
+        // against 0.477): the edges are then summed wave-wide per window, the loads of four windows in flight together.
+        bool direct_edges = true;
+        if constexpr (Tr::kLeaf == kLeafF64) direct_edges = !edge_scans;
+        if constexpr (Tr::kLeaf == kLeafF64) if (edge_scans) {
+            bool pl = fast && lo < a1, pr = fast && b1 < hi;
+            const uint64_t tl = lo / kLeaf, th = hi / kLeaf;
+            for (;;) {
+                const unsigned long long ml = __ballot(pl), mr = __ballot(pr);
+                if ((ml | mr) == 0) break;
+                const uint64_t TL = ml ? readlane_u64(tl, __ffsll((long long)ml) - 1) : 0;
+                const uint64_t TR = mr ? readlane_u64(th, __ffsll((long long)mr) - 1) : 0;
+                Node l0 = none, l1v = none, r0 = none, r1v = none;
+                const uint64_t il = TL * kLeaf + 2 * (uint64_t)lane, ir = TR * kLeaf + 2 * (uint64_t)lane;
+                if (ml) {  // wave-uniform
+                    if (il + 1 < n_sites) Tr::leaf_pair(c, il, l0, l1v);
+                    else if (il < n_sites) l0 = Tr::leaf(c, il);
                 }
+                if (mr) {
+                    if (ir + 1 < n_sites) Tr::leaf_pair(c, ir, r0, r1v);
+                    else if (ir < n_sites) r0 = Tr::leaf(c, ir);
+                }
+                if (ml) {  // suffix: table[x] = sites x .. 127 of the tile
+                    Node ps = l0;
+                    node_add(ps, l1v);
+                    Node s1 = lane_scan_exclusive<Node, true>(ps, lane);
+                    node_add(s1, l1v);
+                    Node s0 = s1;
+                    node_add(s0, l0);
+                    table[2 * lane + 1] = s1;
+                    table[2 * lane] = s0;
+                    if (pl && tl == TL) {
+                        sum = table[lo - TL * kLeaf];  // the first piece: the edges are added left, then right
+                        pl = false;
+                    }
+                }
+                if (mr) {  // prefix: table[128 + x] = sites 0 .. x
+                    Node ps = r0;
+                    node_add(ps, r1v);
+                    Node p0 = lane_scan_exclusive<Node, false>(ps, lane);
+                    node_add(p0, r0);
+                    Node p1 = p0;
+                    node_add(p1, r1v);
+                    table[kLeafF64 + 2 * lane] = p0;
+                    table[kLeafF64 + 2 * lane + 1] = p1;
+                }
+                // a window's right edge is added after its left edge: only once the left one is in (or there is none)
+                if (mr && pr && th == TR && !pl) {
+                    node_add(sum, table[kLeafF64 + (hi - TR * kLeaf) - 1]);
+                    pr = false;
+                }
+            }
+        }
+        if (direct_edges) {
+            for (unsigned long long m = __ballot(fast); m != 0;) {
+                Node acc[4];
+                int src[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    src[u] = m != 0 ? __ffsll((long long)m) - 1 : -1;
+                    if (m != 0) m &= m - 1;
+                    acc[u] = none;
+                    if (src[u] >= 0)  // wave-uniform
+                        ragged_pair<Tr>(acc[u], c, tree, tv, 0, readlane_u64(lo, src[u]), readlane_u64(a1, src[u]),
+                                        readlane_u64(b1, src[u]), readlane_u64(hi, src[u]), lane, n_sites);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (src[u] >= 0) {
+                        const Node e = node_wave_sum(acc[u]);
+                        if (lane == src[u]) sum = e;
+                    }
+            }
         }
         // (2) whole leaves between a1 and A: a suffix scan of the 64 level-1 nodes of lo's level-2 tile
         {
@@ -1190,7 +1262,7 @@ __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, 
                 const Node v = i < n_l1 ? l1[i] : none;
                 Node sfx = lane_scan_exclusive<Node, true>(v, lane);  // the lanes above, in a fixed order
                 node_add(sfx, v);
-                table[lane] = sfx;  // the wave's own LDS row: operations of one wave complete in order
+                table[lane] = sfx;  // the wave's own LDS rows: operations of one wave complete in order
                 if (pend && myT == T) {
                     node_add(sum, table[(a1 - T * kTile2) / kLeaf]);
                     pend = false;
@@ -1293,23 +1365,28 @@ constexpr size_t kSlideLdsBytes = (size_t)4 * 4 * kSlideTile * 16;  // 4 waves x
 template <class Tr>
 __global__ __launch_bounds__(256) void query_group_kernel(typename Tr::Args args, const uint32_t *pos, TreeView tv,
                                                           const pgt_win *win, uint64_t n_win, typename Tr::Row *out,
-                                                          uint64_t n_sites, pgt_dxy_total *tot) {
+                                                          uint64_t n_sites, pgt_dxy_total *tot, uint32_t group, int edge_scans) {
     extern __shared__ __attribute__((aligned(16))) char lds_group[];
-    query_group_body<Tr>(args, pos, tv, win, n_win, out, n_sites, tot, (int)blockIdx.y, lds_group);
+    query_group_body<Tr>(args, pos, tv, win, n_win, out, n_sites, tot, (int)blockIdx.y, group, edge_scans != 0, lds_group);
 }
-// config 3 with a step in the group range: the dxy table in groups; the genotype tables in groups only when the windows
-// are long enough for the int8 tree's level-2 grid (65536 sites), else per window
+// config 3 with the dxy table on the group query; the genotype tables (int8 tree: 65536-site level-2 tiles) follow their
+// own plan: groups too when the windows are long enough, else the sliding query (steps up to 32) or one wave per window
+enum { kHetPerWindow = 0, kHetGroups = 1, kHetSlide = 2 };
 __global__ __launch_bounds__(256) void dxy_het_query_group_kernel(DxyHetQueryArgs f, const uint32_t *pos, const pgt_win *win,
-                                                                  uint64_t n_win, uint64_t n_sites, int het_in_groups) {
+                                                                  uint64_t n_win, uint64_t n_sites, int het_mode, uint32_t group,
+                                                                  int edge_scans, uint32_t het_slide_group) {
     extern __shared__ __attribute__((aligned(16))) char lds_group[];
     if (blockIdx.y == 0) {
-        query_group_body<DxyTraits>(f.dxy, pos, f.tv_dxy, win, n_win, f.dxy_out, n_sites, f.tot, 0, lds_group);
+        query_group_body<DxyTraits>(f.dxy, pos, f.tv_dxy, win, n_win, f.dxy_out, n_sites, f.tot, 0, group, edge_scans != 0, lds_group);
     } else {
         const int k = blockIdx.y - 1;
-        if (het_in_groups)
-            query_group_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0, lds_group);
+        const HetTraits::Args a{f.g[k]};
+        if (het_mode == kHetGroups)
+            query_group_body<HetTraits>(a, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0, group, false, lds_group);
+        else if (het_mode == kHetSlide)
+            query_slide_body<HetTraits>(a, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0, het_slide_group, lds_group);
         else
-            query_body<HetTraits>(HetTraits::Args{f.g[k]}, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0);
+            query_body<HetTraits>(a, pos, f.tv_het[k], win, n_win, f.het_out[k], n_sites, nullptr, 0);
     }
 }
 
@@ -1498,14 +1575,15 @@ int launch_fst_with(BuildFn build, const uint32_t *pos, const double *const *a, 
         if (p0 + np >= n_pairs) if (int rc = record(ev_build1, s, err)) return rc;
         if (n_win > 0) {
             FstTraits::Args args{cols};
-            if (const uint32_t group = slide_group(hints.window_step); group > 1)
+            if (group_query(hints, kLeafF64)) {
+                const uint32_t g = group_size(n_win);
+                hipLaunchKernelGGL(query_group_kernel<FstTraits>, dim3(query_grid((n_win + g - 1) / g), np), dim3(256),
+                                   kGroupLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
+                                   (pgt_dxy_total *)nullptr, g, group_edge_scans(hints));
+            } else if (const uint32_t group = slide_group(hints.window_step); group > 1)
                 hipLaunchKernelGGL(query_slide_kernel<FstTraits>, dim3(query_grid((n_win + group - 1) / group), np), dim3(256),
                                    kSlideLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
                                    (pgt_dxy_total *)nullptr, group);
-            else if (group_query(hints, kLeafF64))
-                hipLaunchKernelGGL(query_group_kernel<FstTraits>, dim3(query_grid((n_win + kWave - 1) / kWave), np), dim3(256),
-                                   kGroupLdsBytes, s, args, pos, tv, win, n_win, out + (uint64_t)p0 * n_win, n,
-                                   (pgt_dxy_total *)nullptr);
             else
                 hipLaunchKernelGGL(query_kernel<FstTraits>, dim3(query_grid(n_win), np), dim3(256), 0, s, args, pos,
                                    tv, win, n_win, out + (uint64_t)p0 * n_win, n, (pgt_dxy_total *)nullptr);
@@ -1545,12 +1623,13 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0) {
         HetTraits::Args args{g};
-        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+        if (group_query(hints, kLeafI8)) {
+            const uint32_t g = group_size(n_win);
+            hipLaunchKernelGGL(query_group_kernel<HetTraits>, dim3(query_grid((n_win + g - 1) / g)), dim3(256),
+                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr, g, 0);
+        } else if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(query_slide_kernel<HetTraits>, dim3(query_grid((n_win + group - 1) / group)), dim3(256),
                                kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr, group);
-        else if (group_query(hints, kLeafI8))
-            hipLaunchKernelGGL(query_group_kernel<HetTraits>, dim3(query_grid((n_win + kWave - 1) / kWave)), dim3(256),
-                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, (pgt_dxy_total *)nullptr);
         else
             hipLaunchKernelGGL(query_kernel<HetTraits>, dim3(query_grid(n_win)), dim3(256), 0, s, args, pos, tv, win,
                                n_win, out, n, (pgt_dxy_total *)nullptr);
@@ -1580,12 +1659,13 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     if (int rc = record(ev_build1, s, err)) return rc;
     if (n_win > 0 || tot) {
         DxyTraits::Args args{p1, p2, n1, n2, minind};
-        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+        if (group_query(hints, kLeafF64)) {
+            const uint32_t g = group_size(n_win);
+            hipLaunchKernelGGL(query_group_kernel<DxyTraits>, dim3(query_grid((n_win + g - 1) / g + 1)), dim3(256),
+                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, tot, g, group_edge_scans(hints));
+        } else if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(query_slide_kernel<DxyTraits>, dim3(query_grid((n_win + group - 1) / group + 1)), dim3(256),
                                kSlideLdsBytes, s, args, pos, tv, win, n_win, out, n, tot, group);
-        else if (group_query(hints, kLeafF64))
-            hipLaunchKernelGGL(query_group_kernel<DxyTraits>, dim3(query_grid((n_win + kWave - 1) / kWave + 1)), dim3(256),
-                               kGroupLdsBytes, s, args, pos, tv, win, n_win, out, n, tot);
         else
             hipLaunchKernelGGL(query_kernel<DxyTraits>, dim3(query_grid(n_win + 1)), dim3(256), 0, s, args, pos, tv,
                                win, n_win, out, n, tot);
@@ -1671,15 +1751,17 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
     if (n_win > 0 || tot) {
         DxyHetQueryArgs q{DxyTraits::Args{p1, p2, n1, n2, minind}, {g1, g2}, tvd, {tvh, tvh1}, dxy_out, tot,
                           {het_out1, het_out2}};
-        if (const uint32_t group = slide_group(hints.window_step); group > 1)
+        if (group_query(hints, kLeafF64)) {
+            const uint32_t g = group_size(n_win), hs = slide_group(hints.window_step);
+            const int het_mode = group_query(hints, kLeafI8) ? kHetGroups : (hs > 1 ? kHetSlide : kHetPerWindow);
+            const uint64_t items = het_mode == kHetPerWindow ? n_win + 1 : (het_mode == kHetSlide ? (n_win + hs - 1) / hs + 1 : (n_win + g - 1) / g + 1);
+            hipLaunchKernelGGL(dxy_het_query_group_kernel, dim3(query_grid(items), 3), dim3(256),
+                               kGroupLdsBytes > kSlideLdsBytes ? kGroupLdsBytes : kSlideLdsBytes, s, q, pos, win, n_win, n, het_mode, g,
+                               group_edge_scans(hints), hs);
+        } else if (const uint32_t group = slide_group(hints.window_step); group > 1)
             hipLaunchKernelGGL(dxy_het_query_slide_kernel, dim3(query_grid((n_win + group - 1) / group + 1), 3), dim3(256),
                                kSlideLdsBytes, s, q, pos, win, n_win, n, group);
-        else if (group_query(hints, kLeafF64)) {
-            const int het_groups = group_query(hints, kLeafI8) ? 1 : 0;
-            const uint64_t items = het_groups ? (n_win + kWave - 1) / kWave + 1 : n_win + 1;
-            hipLaunchKernelGGL(dxy_het_query_group_kernel, dim3(query_grid(items), 3), dim3(256), kGroupLdsBytes, s, q, pos, win,
-                               n_win, n, het_groups);
-        } else
+        else
             hipLaunchKernelGGL(dxy_het_query_kernel, dim3(query_grid(n_win + 1), 3), dim3(256), 0, s, q, pos, win, n_win, n);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_query_kernel", err)) return rc;
     }

@@ -31,7 +31,9 @@ int main(int argc, char **argv) {
         std::fclose(probe);
     }
     parse_window_args(argc, argv, W, S);
-    DeviceOpener device;  // HIP start-up runs beside the parse
+    DeviceOpener device;  // HIP start-up runs beside the parse; PGT_DEVICES=0,1,..: one context and host thread per GPU
+    const bool multi = device.count() > 1;
+    std::vector<DevicePiece> pieces;  // multi-GPU device ingest: one parsed piece of the text per GPU
 
     // chr pos genotype  (hetWindow.cpp:128,139), parsed in parallel chunks straight into the columns
     struct Table {
@@ -66,8 +68,12 @@ int main(int argc, char **argv) {
             static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8};
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
-            on_device = ingest_on_device(c, text.begin(), text.end(), spec, 3, what, argv[1], 1, dtab, runs);
-            n = dtab.n;
+            if (multi) {
+                on_device = ingest_on_devices(device, text.begin(), text.end(), spec, 3, what, argv[1], pieces, runs, &n);
+            } else {
+                on_device = ingest_on_device(c, text.begin(), text.end(), spec, 3, what, argv[1], 1, dtab, runs);
+                n = dtab.n;
+            }
             timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
         }
         if (!on_device) {
@@ -82,7 +88,7 @@ int main(int argc, char **argv) {
     }
 
     SiteWindows sw;
-    sw.build(runs, W, S, [&] { return device.get(); }, &timer);
+    sw.build(runs, W, S, [&] { return device.get(); }, &timer, multi);
     const size_t n_win = sw.n;
     if (n_win == 0) return 0;
 
@@ -90,9 +96,20 @@ int main(int argc, char **argv) {
     pgt_ctx *ctx = device.get();
     RowArray<pgt_het_row> rows(n_win);
     timer.lap("wait for HIP");
-    const uint32_t *pos = on_device ? dtab.col<uint32_t>(1) : tab.pos.data();
-    const int8_t *g = on_device ? dtab.col<int8_t>(2) : tab.g.data();
-    if (sw.tab)
+    set_site_hints(ctx, W, S);  // the strategy follows the tool's arguments, on one GPU as on several
+    const uint32_t *pos = on_device && !multi ? dtab.col<uint32_t>(1) : tab.pos.data();
+    const int8_t *g = on_device && !multi ? dtab.col<int8_t>(2) : tab.g.data();
+    if (multi) {
+        reduce_on_devices<pgt_het_row>(
+            device, sw.win, W, S, pieces, {{1, sizeof(uint32_t)}, {2, sizeof(int8_t)}}, rows.data(),
+            [&](pgt_ctx *c, uint64_t lo, uint64_t n_k, const pgt_win *w, size_t nw, pgt_het_row *out, size_t) {
+                return pgt_het_reduce(c, pos + lo, g + lo, n_k, w, nw, out);
+            },
+            [&](pgt_ctx *c, void *const *d, uint64_t n_k, const pgt_win *w, size_t nw, pgt_het_row *out, size_t bytes) {
+                return pgt_het_reduce_cols(c, static_cast<const uint32_t *>(d[0]), static_cast<const int8_t *>(d[1]), n_k, w, nw, out, bytes);
+            });
+        free_pieces(pieces);
+    } else if (sw.tab)
         check(pgt_het_reduce_tab(ctx, pos, g, n, on_device, sw.tab, rows.data(), rows.size() * sizeof(rows[0])), ctx);
     else if (on_device)
         check(pgt_het_reduce_cols(ctx, pos, g, n, sw.win.data(), n_win, rows.data(), rows.size() * sizeof(rows[0])), ctx);

@@ -667,6 +667,23 @@ inline int device_from_env() {
     const char *d = std::getenv("PGT_DEVICE");
     return d ? std::atoi(d) : 0;
 }
+// PGT_DEVICES=0,1,2,...: the GPUs a run may use (one context and one host thread each); default: the one of PGT_DEVICE.
+// The same ordinal may be listed twice (two contexts on one GPU: how the multi-GPU path is tested on a one-GPU box).
+inline std::vector<int> devices_from_env() {
+    std::vector<int> ids;
+    if (const char *l = std::getenv("PGT_DEVICES")) {
+        for (const char *p = l; *p;) {
+            char *q = nullptr;
+            const long v = std::strtol(p, &q, 10);
+            if (q == p) break;
+            ids.push_back((int)v);
+            p = *q == ',' ? q + 1 : q;
+        }
+        if (ids.size() > 64) ids.resize(64);
+    }
+    if (ids.empty()) ids.push_back(device_from_env());
+    return ids;
+}
 
 inline pgt_ctx *open_or_die() {
     pgt_ctx *ctx = pgt_open(device_from_env());
@@ -674,29 +691,39 @@ inline pgt_ctx *open_or_die() {
     return ctx;
 }
 
-// HIP start-up (50-160 ms) overlapped with parsing: the device is opened on a background thread as
-// soon as the arguments are known to be valid; get() joins it.  Inputs that produce no window never
+// HIP start-up (50-160 ms) overlapped with parsing: the devices are opened on background threads (one per
+// context) as soon as the arguments are known to be valid; get() joins.  Inputs that produce no window never
 // call get() and therefore still run without a GPU, as before.
 class DeviceOpener {
   public:
-    DeviceOpener() : th_([this] {
-        ctx_ = pgt_open(device_from_env());
-        if (!ctx_) err_ = pgt_last_error(nullptr);  // thread-local in the library: copy it here
-    }) {}
-    ~DeviceOpener() {
-        if (th_.joinable()) th_.join();
-        if (ctx_) pgt_close(ctx_);
+    explicit DeviceOpener(std::vector<int> ids = devices_from_env()) : ids_(std::move(ids)), ctx_(ids_.size(), nullptr), err_(ids_.size()) {
+        for (size_t k = 0; k < ids_.size(); ++k)
+            th_.emplace_back([this, k] {
+                ctx_[k] = pgt_open(ids_[k]);
+                if (!ctx_[k]) err_[k] = pgt_last_error(nullptr);  // thread-local in the library: copy it here
+            });
     }
-    pgt_ctx *get() {
-        if (th_.joinable()) th_.join();
-        if (!ctx_) die("libpgtwin: " + err_);
-        return ctx_;
+    ~DeviceOpener() {
+        join();
+        for (pgt_ctx *c : ctx_)
+            if (c) pgt_close(c);
+    }
+    size_t count() const { return ids_.size(); }
+    pgt_ctx *get(size_t k = 0) {
+        join();
+        if (!ctx_[k]) die("libpgtwin: " + err_[k]);
+        return ctx_[k];
     }
 
   private:
-    pgt_ctx *ctx_ = nullptr;
-    std::string err_;
-    std::thread th_;
+    void join() {
+        for (auto &t : th_)
+            if (t.joinable()) t.join();
+    }
+    std::vector<int> ids_;
+    std::vector<pgt_ctx *> ctx_;
+    std::vector<std::string> err_;
+    std::vector<std::thread> th_;
 };
 
 // ---- device-side ingest (pgt_ingest_text) ---------------------------------------------------------
@@ -785,10 +812,10 @@ struct SiteWindows {
     }
     // get_ctx: called only when the table goes to the device (it waits for HIP start-up)
     template <class GetCtx>
-    void build(const Runs &runs, uint32_t W, uint32_t S, GetCtx &&get_ctx, PhaseTimer *timer = nullptr) {
+    void build(const Runs &runs, uint32_t W, uint32_t S, GetCtx &&get_ctx, PhaseTimer *timer = nullptr, bool host_only = false) {
         check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n), nullptr);
         const char *force = std::getenv("PGT_DEVICE_WINTAB");  // 0 / 1: never / always (tests); default by size
-        const bool on_device = force ? std::atoi(force) != 0 : n >= ((size_t)1 << 20);
+        const bool on_device = !host_only && (force ? std::atoi(force) != 0 : n >= ((size_t)1 << 20));  // host_only: the multi-GPU path shards a host table
         if (n == 0) return;
         if (on_device) {
             pgt_ctx *ctx = get_ctx();
@@ -802,6 +829,142 @@ struct SiteWindows {
         }
     }
 };
+
+// Both speed hints from the tool's own arguments: every GPU that reduces a slice of the table — and the single-GPU run —
+// then takes the same query strategy and tree levels, whatever its slice looks like (rows are bitwise independent of the
+// number of GPUs only under identical hints).
+inline void set_site_hints(pgt_ctx *ctx, uint32_t W, uint32_t S) {
+    check(pgt_set_max_window(ctx, W), ctx);
+    check(pgt_set_window_step(ctx, S), ctx);
+}
+
+// ---- several GPUs in one host process (PGT_DEVICES=0,1,...) ---------------------------------------------------
+// The reference is one thread over one stream (fstWindow.cpp:109-155); here the window table is cut into one
+// contiguous block per GPU (pgt_plan_shards: balanced by sites, block starts tree-node aligned, halo <= one window),
+// every GPU gets its own host thread and context, reduces its block from the columns of ITS site range and writes its
+// rows into its slice of the one row array the main thread prints — the CLI-level form of bench.py's N > 1 run.
+// Where the text is parsed on the GPUs (large inputs), the file is cut at line starts into one piece per GPU: each
+// piece crosses its own PCIe link and is parsed where it lands; a GPU then gathers the columns of its shard from the
+// pieces that hold them (mostly its own: device-to-device on one GPU; the halo: a peer copy of <= W + 65535 sites).
+struct DevicePiece {   // one GPU's piece of the text, parsed there
+    pgt_ctx *ctx = nullptr;
+    pgt_ingest *ing = nullptr;
+    uint64_t row0 = 0, rows = 0;  // global site range [row0, row0 + rows)
+};
+struct GatherColumn {  // token of the ingest object, element size
+    int token;
+    size_t elem;
+};
+
+// Cut [b,e) at line starts into `parts` pieces of about equal bytes
+inline std::vector<const char *> cut_at_lines(const char *b, const char *e, size_t parts) {
+    std::vector<const char *> cut(parts + 1, e);
+    cut[0] = b;
+    const size_t len = (size_t)(e - b);
+    for (size_t t = 1; t < parts; ++t) {
+        const char *p = b + len / parts * t;
+        if (p < cut[t - 1]) p = cut[t - 1];
+        const void *nl = p < e ? std::memchr(p, '\n', (size_t)(e - p)) : nullptr;
+        cut[t] = nl ? static_cast<const char *>(nl) + 1 : e;
+    }
+    return cut;
+}
+
+// Parse one file on all devices: piece k on device k.  true: `pieces` (one per device that got data, in file order) and
+// `runs` (stitched at the seams) describe the table, *n_rows its length; false: some piece was refused by the device
+// parser (too many irregular lines) — parse on the host.  Text errors die with the host parser's message.
+inline bool ingest_on_devices(DeviceOpener &device, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what,
+                              const char *path, std::vector<DevicePiece> &pieces, Runs &runs, size_t *n_rows) {
+    const size_t N = device.count();
+    const std::vector<const char *> cut = cut_at_lines(b, e, N);
+    std::vector<pgt_ingest *> ing(N, nullptr);
+    std::vector<int> rc(N, PGT_OK);
+    std::vector<std::string> msg(N);
+    for (size_t k = 0; k < N; ++k) (void)device.get(k);  // all contexts are open (or the run has died) before the threads start
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < N; ++k)
+            th.emplace_back([&, k] {
+                if (cut[k + 1] == cut[k]) return;
+                pgt_ctx *c = device.get(k);
+                rc[k] = pgt_ingest_text(c, cut[k], (size_t)(cut[k + 1] - cut[k]), spec, n_tokens, &ing[k]);
+                if (rc[k] != PGT_OK) msg[k] = pgt_last_error(c);
+            });
+        for (auto &t : th) t.join();
+    }
+    auto free_all = [&] { for (pgt_ingest *g : ing) if (g) pgt_ingest_free(g); };
+    for (size_t k = 0; k < N; ++k)
+        if (rc[k] == PGT_EDOMAIN) { free_all(); return false; }
+    for (size_t k = 0; k < N; ++k)
+        if (rc[k] != PGT_OK) die("libpgtwin: " + msg[k]);
+    uint64_t row = 0;
+    for (size_t k = 0; k < N; ++k) {
+        if (!ing[k]) continue;
+        const int64_t bad = pgt_ingest_bad_line(ing[k]);
+        if (bad >= 0) die(std::string(what) + " on line " + std::to_string(1 + row + (uint64_t)bad) + " of " + path);
+        const uint64_t rows = pgt_ingest_rows(ing[k]);
+        const uint64_t *len = nullptr, *off = nullptr;
+        const uint32_t *nlen = nullptr;
+        const size_t n_runs = pgt_ingest_runs(ing[k], &len, &off, &nlen);
+        for (size_t r = 0; r < n_runs; ++r) runs.add(cut[k] + off[r], cut[k] + off[r] + nlen[r], len[r]);  // add() merges a run that continues across the seam
+        pieces.push_back(DevicePiece{device.get(k), ing[k], row, rows});
+        row += rows;
+        const bool stopped = pgt_ingest_blank_before_end(ing[k]) != 0;
+        ing[k] = nullptr;
+        if (stopped) break;  // a blank line ends the data (fstWindow.cpp:125): the pieces behind it are not part of the table
+    }
+    free_all();
+    *n_rows = (size_t)row;
+    return true;
+}
+inline void free_pieces(std::vector<DevicePiece> &pieces) {
+    for (DevicePiece &p : pieces)
+        if (p.ing) pgt_ingest_free(p.ing);
+    pieces.clear();
+}
+
+// The sharded reduce.  host_reduce(ctx, site_lo, n_sites, win, n_win, out, out_bytes): columns on the host (the entry point
+// uploads the slice); cols_reduce(ctx, dcols, n_sites, win, n_win, out, out_bytes): dcols[c] = this GPU's gathered copy of
+// gather[c].  Exactly one of the two paths is taken: pieces empty -> host columns.
+template <class Row, class HostReduce, class ColsReduce>
+void reduce_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, uint32_t W, uint32_t S, std::vector<DevicePiece> &pieces,
+                       const std::vector<GatherColumn> &gather, Row *rows, HostReduce host_reduce, ColsReduce cols_reduce) {
+    const size_t N = device.count();
+    std::vector<pgt_shard> shard(N);
+    check(pgt_plan_shards(win.data(), win.size(), (uint32_t)N, shard.data()), nullptr);
+    for (size_t k = 0; k < N; ++k) (void)device.get(k);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < N; ++k)
+        th.emplace_back([&, k] {
+            const pgt_shard sh = shard[k];
+            const size_t n_local = (size_t)(sh.win_end - sh.win_begin);
+            if (n_local == 0) return;
+            pgt_ctx *ctx = device.get(k);
+            set_site_hints(ctx, W, S);
+            std::vector<pgt_win> local(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end);
+            for (pgt_win &w : local) { w.lo -= sh.site_lo; w.hi -= sh.site_lo; }
+            const uint64_t n_sites = sh.site_hi - sh.site_lo;
+            Row *out = rows + sh.win_begin;
+            if (pieces.empty()) {
+                check(host_reduce(ctx, sh.site_lo, n_sites, local.data(), n_local, out, n_local * sizeof(Row)), ctx);
+                return;
+            }
+            std::vector<void *> dcols(gather.size(), nullptr);
+            for (size_t c = 0; c < gather.size(); ++c) {
+                check(pgt_dev_alloc(ctx, (size_t)n_sites * gather[c].elem + 16, &dcols[c]), ctx);
+                for (const DevicePiece &p : pieces) {
+                    const uint64_t g0 = std::max<uint64_t>(sh.site_lo, p.row0), g1 = std::min<uint64_t>(sh.site_hi, p.row0 + p.rows);
+                    if (g0 >= g1) continue;
+                    const char *src = static_cast<const char *>(pgt_ingest_column(p.ing, gather[c].token)) + (g0 - p.row0) * gather[c].elem;
+                    check(pgt_dev_copy(ctx, static_cast<char *>(dcols[c]) + (g0 - sh.site_lo) * gather[c].elem, p.ctx, src,
+                                       (size_t)(g1 - g0) * gather[c].elem), ctx);
+                }
+            }
+            check(cols_reduce(ctx, dcols.data(), n_sites, local.data(), n_local, out, n_local * sizeof(Row)), ctx);
+            for (void *d : dcols) check(pgt_dev_free(ctx, d), ctx);
+        });
+    for (auto &t : th) t.join();
+}
 
 // Window size / step size as fstWindow.cpp:51-64 reads them (atoi); zero, negative or
 // non-numeric values are refused.  The reference only warns for a bad step and then crashes

@@ -469,6 +469,62 @@ def test_gpu_ingest_cli_equals_host_parser(hosts, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
+    """PGT_DEVICES=0,0 and 0,0,0 — several contexts on the one GPU of this box, one host thread each: the window table is
+    cut by pgt_plan_shards, every context reduces its block from the columns of its own site range, and the main thread
+    prints.  stdout, stderr and the exit code must be those of the single-device run, byte for byte: on the
+    reference-made goldens (host parser and device parser: with the latter the TEXT is cut at line starts, one piece per
+    context, and a context gathers its shard's columns from the pieces), on inputs with a blank-line stop or a bad line in
+    a later piece, and on a 10^7-line table for fstWindow (steps 10000 and 100: per-window and group query) and hetWindow."""
+    import synth
+
+    def runs(cmd, **env):
+        one = run(cmd, env=dict(os.environ, **env))
+        for devs in ("0,0", "0,0,0"):
+            many = run(cmd, env=dict(os.environ, PGT_DEVICES=devs, **env))
+            assert (many.returncode, many.stdout, many.stderr) == (one.returncode, one.stdout, one.stderr), (cmd, devs, env, many.stderr[-300:])
+        return one
+
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::3]
+    for c in cases:
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        for ingest in ("0", "1"):
+            r = runs([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], PGT_GPU_INGEST=ingest)
+            assert r.returncode == 0
+            tsv_equal(r.stdout, c["stdout"], 4)
+    # the data ends at a blank line in the first piece; a bad line in the last piece (the message carries the GLOBAL line number)
+    f = tmp_path / "stop.txt"
+    body = "".join(f"c{1 + i // 40}\t{i + 1}\t0.0{i % 7}\t0.{1 + i % 5}\n" for i in range(200))
+    f.write_text(body[: len(body) // 5] + "\n" + body[len(body) // 5:])
+    assert runs([hosts["fstWindow"], str(f), "7", "3"], PGT_GPU_INGEST="1").returncode == 0
+    lines = body.splitlines(True)
+    f.write_text("".join(lines[:190]) + "c5\t191\tx\t0.1\n" + "".join(lines[191:]))
+    r = runs([hosts["fstWindow"], str(f), "7", "3"], PGT_GPU_INGEST="1")
+    assert r.returncode == 255 and "line 191" in r.stderr
+    # 10^7 lines
+    rng = np.random.default_rng(31)
+    n = 10_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 7, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    big = tmp_path / "big.fst.txt"
+    oracle.write_fst_text(str(big), chr_ids, pos, a, b)
+    for W, S in ((50_000, 10_000), (50_000, 100)):
+        for ingest in ("1", "0"):
+            r = runs([hosts["fstWindow"], str(big), str(W), str(S)], PGT_GPU_INGEST=ingest)
+            assert r.returncode == 0 and len(r.stdout.splitlines()) > n // S - 7 * (W // S + 1)
+    os.unlink(big)
+    g = synth.het_column(rng, n)
+    bigh = tmp_path / "big.het.txt"
+    with open(bigh, "w") as fh:
+        for lo in range(0, n, 1_000_000):
+            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    r = runs([hosts["hetWindow"], str(bigh), "50000", "10000"], PGT_GPU_INGEST="1")
+    assert r.returncode == 0 and len(r.stdout.splitlines()) > 900
+
+
+@pytest.mark.gpu
 def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
     """Where oracle/_ref holds the compiled, unmodified reference tools (this container, and the GPU box, which
     receives them with the snapshot): fresh random inputs — other seeds than the committed goldens — through the
