@@ -266,7 +266,7 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     ctx.set_window_step(0)
     ctx.set_max_window(W)
     out["fst_1e7_small_step_query"] = {"config": "fstWindow 1e7 sites, W=50000, S=1 (9.95e6 windows) and S=100 (99501 windows): query kernel only, ms; "
-                                                 "the product takes the group query for both (pgt_set_window_step <= 512, windows >= 16384 sites)",
+                                                 "the product takes the group query for both (pgt_set_window_step <= 1024, windows >= 16384 sites)",
                                        **q}
     return out
 

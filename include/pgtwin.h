@@ -212,17 +212,19 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
  * GPUs only under identical hints (the strategies add in different orders). */
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
 /* Typical distance, in sites, between the starts of consecutive windows of the following *_dev calls
- * (the tools' step size S); 0 (the default) = unknown.  With a step of at most 32 sites the queries
- * use the SLIDING strategy: one wave answers a group of consecutive windows from one suffix scan of
- * the sites around their starts, one prefix scan around their ends and ONE tree query for the
- * interior they share, instead of one tree query per window — the regime of `-winsize W -stepsize 1`
- * (fstWindow.cpp:80-83,95-99: the reference re-sums W sites and shifts W-S per window there); with a step
- * of 33 .. 512 sites (and windows of at least two level-2 tiles: 16384 sites for the f64 trees) the GROUP
- * strategy: 64 consecutive windows per wave share the scans of the 128-site tiles under their ends, the scans
- * of the level-1 nodes beside them and the interior query (`-winsize 50000 -stepsize 100`).  Speed
- * only: any table is answered correctly whatever the hint (groups that do not slide fall back to the
- * per-window query); sums are taken in a different order, so the last bits of a float may differ
- * between the two strategies.  The host-buffer entry points derive the hint from the table. */
+ * (the tools' step size S); 0 (the default) = unknown: one wave per window.  The step selects the query
+ * strategy for the regime `-winsize W -stepsize S` with S << W, where the reference re-sums W sites and
+ * shifts W-S per window (fstWindow.cpp:80-83,95-99):
+ *   GROUP    1 <= S <= 1024 and a longest-window hint of at least two level-2 tiles (16384 sites for the f64
+ *            trees, 131072 for the genotype tree): one wave answers up to 64 CONSECUTIVE windows, one per lane;
+ *            they share the scans of the 128-site tiles under their ends (S <= 64), the scans of the level-1
+ *            nodes beside those and ONE tree query per distinct interior;
+ *   SLIDING  S <= 32 with shorter (or unknown) windows: per-site suffix / prefix scans of the 128-site tiles a
+ *            group of 128/S + 1 windows starts and ends in, and one tree query for the interior they share.
+ * Speed only: any table is answered correctly whatever the hint (windows a strategy does not fit fall back to
+ * the plain range query); the strategies add in different orders, so the last bits of a float may differ between
+ * them — under one pair of hints, rows are bitwise independent of which windows share a wave and of the number of
+ * GPUs.  The host-buffer entry points derive the hint from the table while it is unset. */
 int pgt_set_window_step(pgt_ctx *ctx, uint64_t step_sites);
 
 /* ---- per-kernel timing (HIP events on the launch stream; for bench.py's roofline) ------- */

@@ -127,7 +127,7 @@ struct Hints {
 // S = 8 0.65 against 1.80, S = 32 0.60 against 1.55; profiles/r03/measure_query_1e8_strategies.md).  Shorter windows
 // with step <= kSlideMaxStep: the sliding query (per-site scans of 128-site tiles; it needs only 256-site windows).
 constexpr uint64_t kSlideMaxStep = 32;
-constexpr uint64_t kGroupMaxStep = 512;  // above, a group's 64 starts span too many level-2 tiles and there are too few groups to fill the chip
+constexpr uint64_t kGroupMaxStep = 1024;  // above, a group's starts span too many level-2 tiles and there are too few groups to fill the chip (10^8 sites: a tie at 2048)
 // Windows per wave of the sliding query for a given step (0 or 1 = not the sliding query).
 inline uint32_t slide_group(uint64_t step) {
     if (step == 0 || step > kSlideMaxStep) return 1;

@@ -497,9 +497,10 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
     # the data ends at a blank line in the first piece; a bad line in the last piece (the message carries the GLOBAL line number)
     f = tmp_path / "stop.txt"
     body = "".join(f"c{1 + i // 40}\t{i + 1}\t0.0{i % 7}\t0.{1 + i % 5}\n" for i in range(200))
-    f.write_text(body[: len(body) // 5] + "\n" + body[len(body) // 5:])
-    assert runs([hosts["fstWindow"], str(f), "7", "3"], PGT_GPU_INGEST="1").returncode == 0
     lines = body.splitlines(True)
+    f.write_text("".join(lines[:40]) + "\n" + "".join(lines[40:]))  # a blank line after line 40: the data ends there
+    r = runs([hosts["fstWindow"], str(f), "7", "3"], PGT_GPU_INGEST="1")
+    assert r.returncode == 0 and r.stdout.splitlines()[-1].split("\t")[2] == "40"
     f.write_text("".join(lines[:190]) + "c5\t191\tx\t0.1\n" + "".join(lines[191:]))
     r = runs([hosts["fstWindow"], str(f), "7", "3"], PGT_GPU_INGEST="1")
     assert r.returncode == 255 and "line 191" in r.stderr

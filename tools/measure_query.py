@@ -37,13 +37,13 @@ def main():
         nw = win_h.size
         del win_h
         # The hint selects the strategy, and every strategy answers any table correctly: so each can be timed at every S by
-        # passing a hint inside its range (sliding: <= 32 with the longest window unknown, group: 1 .. 512) — the product passes the true step.
+        # passing a hint inside its range (sliding: <= 32 with the longest window unknown, group: 1 .. 1024) — the product passes the true step.
         cases = [("per-window", 0)]
         if S <= 32:
             cases.append(("sliding", S))
-        cases.append(("group", min(S, 512)))
+        cases.append(("group", min(S, 1024)))
         out = [torch.empty(nw * FST_ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(len(cases))]
-        chosen = "group" if (S <= 512 and W >= 16384) else ("sliding" if S <= 32 else "per-window")
+        chosen = "group" if (S <= 1024 and W >= 16384) else ("sliding" if S <= 32 else "per-window")
         for k, (name, hint) in enumerate(cases):
             ctx.set_window_step(hint)
             ctx.set_max_window(0 if name == "sliding" else W)  # an unknown longest window rules the group query out: the sliding one runs
