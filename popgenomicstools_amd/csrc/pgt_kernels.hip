@@ -345,11 +345,14 @@ __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const 
 // BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
 // window table — ONE stream of 26 B/site (p1,p2 f64 + n1,n2 i32 + g1,g2 i8).  The wave that owns level-2
 // tile t of the dxy tree (8192 sites) also owns the SAME 8192 sites of both genotype columns: that is
-// exactly one het work item (8 leaf tiles of 1024 sites, 8 KiB per column).  Its 16 genotype loads (one
-// 16-byte load per lane each) ride along with the 16 batches of dxy loads, one per batch, so they are in
-// flight together with 16 dxy loads and cost no round trip of their own; the byte counts go through the
-// same packed-word popcounts as het_build_body and ONE wave reduction per leaf (nonmissing and nhet packed
-// into one register: both are at most 1024).  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
+// exactly one het work item (8 leaf tiles of 1024 sites, 8 KiB per column).  A genotype column's 8 KiB are
+// requested in ONE burst of eight 16-byte loads per lane — column 0 with the first batch of dxy loads of the
+// tile, column 1 with the batch in the middle — so they are in flight together with the dxy loads and cost no
+// round trip of their own; the byte counts go through the same packed-word popcounts as het_build_body and
+// ONE wave reduction per leaf (nonmissing and nhet packed into one register: both are at most 1024).
+// Measured in one process, interleaved (profiles/r03/fused_ab.txt; % of the HBM peak on 26 B/site at 10^8 /
+// 10^9 sites): 8 dxy loads per batch + bursts 79.6 / 80.8 (this kernel), 8 + one genotype load per batch
+// 78.6 / 80.6, 16 dxy loads per batch 77.4 / 79.0 with either genotype schedule.  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
 // LDS stage beside the tile's dxy row and leave with it (deferred stores, see NodeStage); level 2 of the het
 // trees comes from tree_up_kernel as in the separate build.  Node values and tree layout are those of the
 // separate kernels bit for bit (integer counts; the dxy arithmetic is the same code).
@@ -376,9 +379,9 @@ __device__ __forceinline__ uint32_t het_count_packed(const uint4 &w) {  // nonmi
     return nm | (nh << 16);
 }
 
-template <int U = 4>  // dxy leaf tiles per batch; 64 / U batches per tile must cover the 16 genotype loads (U <= 4)
+template <int U = 2>  // dxy leaf tiles per batch: 4 U loads in flight per lane (+ 8 while a genotype burst is out)
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
-    static_assert(kRadix / U >= 2 * kHetChunk, "one genotype load per batch");
+    static_assert(kRadix % (2 * U) == 0, "a batch starts in the middle of the tile");
     static_assert((uint64_t)kLeafF64 * kRadix == (uint64_t)kLeafI8 * kHetChunk, "a dxy level-2 tile is one het work item");
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -420,9 +423,12 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
             for (int j = 0; j < kRadix; j += U) {
                 double2 x1[U], x2[U];
                 int2 k1[U], k2[U];
-                const int hb = j / U;  // batch index: batches 0..15 carry genotype load hb (column hb / 8, leaf hb % 8)
-                uint4 gw = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-                if (hb < 2 * kHetChunk) gw = load16_nt((hb < kHetChunk ? h0 : h1) + (hb & (kHetChunk - 1)) * kWave + lane);  // wave-uniform
+                uint4 gb[kHetChunk];
+                const bool burst = j == 0 || j == kRadix / 2;  // wave-uniform: genotype column 0 / 1
+                if (burst) {
+#pragma unroll
+                    for (int u = 0; u < kHetChunk; ++u) gb[u] = load16_nt((j == 0 ? h0 : h1) + u * kWave + lane);
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
@@ -438,9 +444,12 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
                     acc = node_wave_sum(acc);
                     if (lane == j + u) keep = acc;
                 }
-                if (hb < 2 * kHetChunk) {  // wave-uniform
-                    const uint32_t c = wave_sum(het_count_packed(gw));  // both fields <= 1024: no carry between them
-                    if (lane == hb) hkeep = c;
+                if (burst) {
+#pragma unroll
+                    for (int u = 0; u < kHetChunk; ++u) {
+                        const uint32_t c = wave_sum(het_count_packed(gb[u]));  // both fields <= 1024: no carry between them
+                        if (lane == (j == 0 ? 0 : kHetChunk) + u) hkeep = c;
+                    }
                 }
             }
         } else {  // the last, partial tile: site by site, sites beyond n count as nothing
@@ -1129,6 +1138,10 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
 // that depends on the window alone (fixed lane order of the scans; range_partial for the interior): rows are
 // bitwise independent of which windows share a wave, hence of the number of GPUs.  Windows the cut does not
 // fit (shorter than the level-2 grid allows: A > B) take the plain range query, one by one.
+// (Round 3, tried and dropped: the five pieces kept in separate registers, with the coordinates and the level-1 nodes of
+// the first start / end tile requested before the edge scans so that a group costs two round trips instead of six in a
+// row — 81-89 VGPRs, 5 instead of 7 waves per SIMD, and no faster: S = 1 2.96 vs 2.85 ms per 10^8 windows, S = 100
+// 0.496 vs 0.456 ms per 10^6; profiles/r03/measure_query_1e8_prefetch_variant.md.  The kernel is not latency-bound.)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_lane) {  // wave-uniform src_lane
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
@@ -1527,11 +1540,10 @@ int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
                               "hipFuncSetAttribute", err))
             return rc;
-    const void *fused[] = {reinterpret_cast<const void *>(dxy_het_build_kernel<2>), reinterpret_cast<const void *>(dxy_het_build_kernel<4>)};
-    for (const void *k : fused)
-        if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDxyHetStageBytes),
-                              "hipFuncSetAttribute", err))
-            return rc;
+    if (int rc = hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(dxy_het_build_kernel<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDxyHetStageBytes),
+                          "hipFuncSetAttribute", err))
+        return rc;
     return PGT_OK;
 }
 
@@ -1739,10 +1751,8 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         const uint64_t n_items = het_items(n);  // == td.count[1]: a dxy level-2 tile is one het work item
         DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], tvd, tvh};
         const dim3 grid(build_grid(td.count[1], kFstBuildBlocks));
-        if (td.count[1] <= kFstSmallTiles)  // 17 instead of 9 loads in flight per lane for short inputs (see fst_build_launch)
-            hipLaunchKernelGGL(dxy_het_build_kernel<4>, grid, dim3(256), kDxyHetStageBytes, s, f);
-        else
-            hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kDxyHetStageBytes, s, f);
+        // one instantiation at every size: unlike the single-statistic builds, 16 dxy loads per batch lose here (see the kernel)
+        hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kDxyHetStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
         if (int rc = launch_upper<NodeHet>(th, tvh, 2, s, err, 1, n_items * kHetChunk)) return rc;  // both genotype trees per launch
