@@ -447,6 +447,9 @@ def main():
     ctx.set_profiling(False)
     build_avg = float(np.mean(build_ms))
     achieved = BYTES_PER_SITE * n_tables * n / (build_avg * 1e-3) / 1e9  # GB/s
+    # HBM traffic of one build launch from the PMC passes committed under profiles/r03 (the same kernel on the same
+    # 10^9-site, one-pair workload): 1.008 x the algorithmic bytes — every column byte is fetched once
+    traffic = (2 * 7812576.5 + 124003.5) * 1024.0 if (n == 1_000_000_000 and n_tables == 1) else None
 
     # --- sanity: a sample of windows against float64 sums taken by torch (independent path)
     if rank == 0:
@@ -503,8 +506,12 @@ def main():
             "rows_sha256": sha,
             "rows_check": rows_check,
             "roofline": {"bound": "hbm", "kernel": "fst_build_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_source": "profiles/r02/pmc_counters.csv (separate rocprofv3 --pmc passes; not measured by this run)",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch of the build kernel (read + written)",
+                         "traffic_source": "profiles/r03/pmc_counters.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                                           "`bench.py --steps 3 --warmup 1 --no-cpu --headline-only` (tools/collect_profiles.sh), 9 dispatches each: "
+                                           "2 x 7812576.5 KiB (gfx950: FETCH_SIZE counts half of a wide coalesced read) + 124003.5 KiB written; a "
+                                           "constant of the committed profile, not measured by this run (null for any other workload)",
                          "kernel_ms": build_avg, "query_kernel_ms": float(np.mean(query_ms)),
                          "algorithmic_bytes_per_launch": BYTES_PER_SITE * n_tables * n, "sites_per_launch": n},
             "cpu_baseline": cpu,
