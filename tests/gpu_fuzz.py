@@ -51,6 +51,16 @@ def main():
             S = int(rng.integers(1, min(W, 32) + 1))
         if n * (W / S) > 4e8:  # keep the oracle's O(N*W/S) affordable
             S = max(S, W // 50 + 1)
+        if kind in ("fst", "het", "dxy_fixed", "af") and rng.random() < 0.35:
+            # the group query's regime: steps 1 .. 1024 with windows of at least two level-2 tiles (16384 sites for the f64
+            # trees, 131072 for the genotype tree), window lengths on and beside the 128 / 8192-site grids, n sized so that
+            # the oracle's O(N*W/S) stays affordable
+            W = int(rng.choice([rng.integers(16_384, 60_000), rng.integers(131_072, 300_000), 16_384, 16_383, 24_576, 24_577, 50_000]))
+            S = int(rng.choice([rng.integers(1, 65), rng.integers(65, 1025), 1, 64, 65, 128, 1024]))
+            n = int(min(rng.integers(W // 2, 2_500_000), max(W // 2, 4e8 * S / W)))
+            n_chr = int(rng.integers(1, 6))
+            chr_ids, pos = synth.chromosomes(rng, n, n_chr, equal=bool(rng.random() < 0.3))
+            counts["(group-regime geometries)"] = counts.get("(group-regime geometries)", 0) + 1
         try:
             if kind == "fst":
                 a, b = synth.fst_columns(rng, n)
