@@ -7,7 +7,9 @@
 //   2. parse_table on a generated table, single- and multi-chunk;
 //   3. ColumnCache: store -> load gives the same bytes; truncated, foreign and size-mismatched files are refused;
 //   4. Text on gzip input: a bgzf file (block-parallel inflate), a plain gzip file and a bgzf file followed by a
-//      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused.
+//      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused;
+//   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
+//      per piece and stitched with Runs::add are the runs of the whole text.
 #include <dirent.h>
 
 #include <cinttypes>
@@ -305,6 +307,40 @@ int main(int argc, char **argv) {
             CHECK(!t3.open((dir + "/t.hurt.gz").c_str()));
         }
         for (const char *n : {"/t.bgzf.gz", "/t.plain.gz", "/t.mixed.gz", "/t.hurt.gz"}) std::remove((dir + n).c_str());
+    }
+    {   // 5. the multi-GPU text cut (cut_at_lines) and the stitching of chromosome runs across the seams (Runs::add)
+        for (int trial = 0; trial < 300; ++trial) {
+            std::string text;
+            Runs whole;
+            const int n_lines = (int)(rng() % 400);
+            int chr = 0;
+            for (int i = 0; i < n_lines; ++i) {
+                if (rng() % 17 == 0) ++chr;
+                const std::string name = "c" + std::to_string(chr);
+                whole.add(name.data(), name.data() + name.size());
+                text += name + "\t" + std::to_string(i + 1) + "\t0." + std::to_string(rng() % 1000) + "\t0.5\n";
+            }
+            if (n_lines && rng() % 4 == 0) text.pop_back();  // last line without newline
+            const size_t parts = 1 + rng() % 9;
+            const char *b = text.data(), *e = b + text.size();
+            const std::vector<const char *> cut = cut_at_lines(b, e, parts);
+            CHECK(cut.size() == parts + 1 && cut.front() == b && cut.back() == e);
+            Runs stitched;
+            for (size_t k = 0; k < parts; ++k) {
+                CHECK(cut[k] <= cut[k + 1]);
+                CHECK(cut[k] == b || cut[k] == e || cut[k][-1] == '\n');  // every piece starts at a line start
+                Runs piece;  // what the parser of piece k reports: runs with names pointing into the text
+                for (const char *p = cut[k]; p < cut[k + 1];) {
+                    const char *tab = static_cast<const char *>(std::memchr(p, '\t', (size_t)(cut[k + 1] - p)));
+                    piece.add(p, tab);
+                    const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(cut[k + 1] - p)));
+                    p = nl ? nl + 1 : cut[k + 1];
+                }
+                for (size_t r = 0; r < piece.name.size(); ++r)
+                    stitched.add(piece.name[r].data(), piece.name[r].data() + piece.name[r].size(), piece.len[r]);
+            }
+            CHECK(stitched.name == whole.name && stitched.len == whole.len);
+        }
     }
     std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);
     return fails ? 1 : 0;
