@@ -1168,31 +1168,26 @@ def test_sliding_query_with_batched_pairs_and_fused_statistics(pgt, ctx):
     tp = t(pos.view(np.int32))
     ta, tb = [t(c[0]) for c in cols], [t(c[1]) for c in cols]
     for W, S in ((3_000, 1), (20_000, 100), (140_000, 300)):  # sliding; group (dxy in groups, het per window); group for both trees
-      win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
-      wt = windows_to_device(win, dev)
-      ctx.set_max_window(W)
-      ctx.set_window_step(S)
-      try:
-          out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, wt)
-          torch.cuda.synchronize()
-          rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
-          for p in range(n_pairs):
-              single, _ = ctx.fst_reduce_dev(tp, ta[p], tb[p], wt)
-              torch.cuda.synchronize()
-              assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
-          p1, p2, n1, n2 = synth.dxy_columns(rng, n)
-          g1 = synth.het_column(rng, n).astype(np.int8)
-          g2 = synth.het_column(rng, n).astype(np.int8)
-          d, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), t(g1), t(g2), 5, wt)
-          ds, tots, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wt)
-          hs, _ = ctx.het_reduce_dev(tp, t(g2), wt)
-          torch.cuda.synchronize()
-          assert rows_from_device(d, DXY_ROW_DTYPE).tobytes() == rows_from_device(ds, DXY_ROW_DTYPE).tobytes()
-          assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tots, DXY_TOTAL_DTYPE).tobytes()
-          assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
-      finally:
-        ctx.set_window_step(0)
-        ctx.set_max_window(0)
+        win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), W, S)
+        wt = windows_to_device(win, dev)
+        with ctx.hints(W, S):
+            out, _ = ctx.fst_reduce_pairs_dev(tp, ta, tb, wt)
+            torch.cuda.synchronize()
+            rows = rows_from_device(out, FST_ROW_DTYPE).reshape(n_pairs, win.size)
+            for p in range(n_pairs):
+                single, _ = ctx.fst_reduce_dev(tp, ta[p], tb[p], wt)
+                torch.cuda.synchronize()
+                assert rows_from_device(single, FST_ROW_DTYPE).tobytes() == rows[p].tobytes()
+            p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+            g1 = synth.het_column(rng, n).astype(np.int8)
+            g2 = synth.het_column(rng, n).astype(np.int8)
+            d, tot, h1, h2, _ = ctx.dxy_het_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), t(g1), t(g2), 5, wt)
+            ds, tots, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wt)
+            hs, _ = ctx.het_reduce_dev(tp, t(g2), wt)
+            torch.cuda.synchronize()
+            assert rows_from_device(d, DXY_ROW_DTYPE).tobytes() == rows_from_device(ds, DXY_ROW_DTYPE).tobytes()
+            assert rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tots, DXY_TOTAL_DTYPE).tobytes()
+            assert rows_from_device(h2, HET_ROW_DTYPE).tobytes() == rows_from_device(hs, HET_ROW_DTYPE).tobytes()
 
 
 def test_sharded_dxy_scan_single_process(pgt, ctx):
