@@ -209,7 +209,10 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
  * exist.  The host-buffer / *_cols entry points derive a hint from the table only while it is unknown (0): a caller
  * that reduces SLICES of one table on several GPUs sets both hints from the whole table (W, S), so that every
  * slice — and the single-GPU run — takes the same query strategy: rows are bitwise independent of the number of
- * GPUs only under identical hints (the strategies add in different orders). */
+ * GPUs only under identical hints (the strategies add in different orders).
+ * The value also stands for the TYPICAL window length when the query strategy is chosen (pgt_set_window_step): pass the
+ * tools' W, not a loose upper bound — the group strategy is taken for windows of at least two level-2 tiles, and with
+ * windows much shorter than the hint it degenerates to one range query after the other (correct, slow). */
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
 /* Typical distance, in sites, between the starts of consecutive windows of the following *_dev calls
  * (the tools' step size S); 0 (the default) = unknown: one wave per window.  The step selects the query

@@ -571,6 +571,26 @@ def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
             exact += 1
             total += 1
     assert exact >= total - 3  # fstWindow rows may differ in the sixth digit of a ratio; in practice none does
+    # S << W with windows of two and more level-2 tiles: the group query (steps 1 .. 1024), the sliding query (short
+    # windows, steps up to 32) and one wave per window, each against the reference's own re-summation
+    # (fstWindow.cpp:80-83,95-99) — larger tables than the fixtures can hold
+    import synth
+    nrng = np.random.default_rng(20261004)
+    for n, n_chr, W, S in ((60_000, 3, 20_000, 1), (90_000, 2, 16_384, 7), (150_000, 4, 50_000, 100), (150_000, 1, 24_577, 64),
+                           (200_000, 5, 30_000, 1000), (30_000, 2, 3_000, 5), (200_000, 3, 50_000, 2500), (400_000, 2, 140_000, 300)):
+        chr_ids, pos = synth.chromosomes(nrng, n, n_chr, equal=False)
+        a_, b_ = synth.fst_columns(nrng, n)
+        g_ = synth.het_column(nrng, n)
+        f = tmp_path / "big.txt"
+        f.write_text("".join(f"chr{c}\t{p}\t{x:.6f}\t{y:.6f}\n" for c, p, x, y in zip(chr_ids, pos, a_, b_)))
+        ref = run([oracle_bind.ref_binary("fstWindow"), str(f), str(W), str(S)])
+        mine = run([hosts["fstWindow"], str(f), str(W), str(S)])
+        assert mine.returncode == 0 and ref.returncode == 0 and len(ref.stdout.splitlines()) > 10, (W, S, mine.stderr)
+        tsv_equal(mine.stdout, ref.stdout, 4)
+        f.write_text("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids, pos, g_)))
+        ref = run([oracle_bind.ref_binary("hetWindow"), str(f), str(W), str(S)])
+        mine = run([hosts["hetWindow"], str(f), str(W), str(S)])
+        assert mine.returncode == 0 and mine.stdout == ref.stdout, ("hetWindow", W, S)
 
 
 @pytest.mark.gpu
