@@ -71,10 +71,19 @@ struct HintScope {
         if (saved.max_window == 0) c->hints.max_window = m;  // an explicit hint (the caller knows the whole table) stays
         // typical step = median distance between consecutive window starts (a sample from the middle of the
         // table: chromosome boundaries and the Q1 carry make a few distances irregular)
-        std::vector<uint64_t> d;
+        std::vector<uint64_t> d, len;
         const uint64_t from = n_win > 4097 ? n_win / 2 - 2048 : 0, to = n_win > 4097 ? from + 4096 : (n_win ? n_win - 1 : 0);
-        for (uint64_t i = from; i < to; ++i)
+        for (uint64_t i = from; i < to; ++i) {
             if (win[i + 1].lo >= win[i].lo) d.push_back(win[i + 1].lo - win[i].lo);
+            if (win[i].hi >= win[i].lo) len.push_back(win[i].hi - win[i].lo);
+        }
+        // the typical (median) window length decides whether the group query fits, not the longest window: base-pair
+        // windows (dxyWindow) vary in their number of sites, and a strategy chosen for the longest would run the fallback
+        // of most (an explicit pgt_set_max_window stands for both)
+        if (saved.max_window == 0 && !len.empty()) {
+            std::nth_element(len.begin(), len.begin() + len.size() / 2, len.end());
+            c->hints.typical_window = len[len.size() / 2];
+        }
         uint64_t step = 0;
         if (!d.empty()) {
             std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
@@ -215,6 +224,7 @@ int pgt_set_profiling(pgt_ctx *ctx, int enabled) {
 int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites) {
     if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
     ctx->hints.max_window = max_window_sites;
+    ctx->hints.typical_window = 0;  // the explicit value stands for the typical length too
     return PGT_OK;
 }
 

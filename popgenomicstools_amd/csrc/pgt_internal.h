@@ -118,7 +118,8 @@ inline AfTree af_tree_view(const TreeLayout &t, int n_vals, void *tree, int leve
 // Speed-only hints of a context (pgt_set_max_window, pgt_set_window_step); 0 = unknown.
 struct Hints {
     uint64_t max_window = 0;   // longest window in sites: tree levels with larger nodes are not built
-    uint64_t window_step = 0;  // typical distance between consecutive window starts: selects the sliding query
+    uint64_t window_step = 0;  // typical distance between consecutive window starts: selects the query strategy
+    uint64_t typical_window = 0;  // typical window length where the library saw the table itself (host tables); 0: max_window stands for it
 };
 // ---- query strategies, chosen from the hints alone (the same on every rank when the hints are) ----------------
 // step == 0 (unknown) or large: one wave per window.  0 < step <= kGroupMaxStep and windows of at least two level-2
@@ -136,7 +137,8 @@ inline uint32_t slide_group(uint64_t step) {
 }
 // leaf = sites per level-1 node of the statistic's tree (its level-2 tiles are 64 leaves)
 inline bool group_query(const Hints &h, uint64_t leaf) {
-    return h.window_step > 0 && h.window_step <= kGroupMaxStep && h.max_window >= 2 * leaf * kRadix;
+    const uint64_t typical = h.typical_window ? h.typical_window : h.max_window;
+    return h.window_step > 0 && h.window_step <= kGroupMaxStep && typical >= 2 * leaf * kRadix;
 }
 // the group query's ragged ends: shared 128-site tile scans up to this step, per window above (see query_group_body)
 inline int group_edge_scans(const Hints &h) { return h.window_step <= 64 ? 1 : 0; }
