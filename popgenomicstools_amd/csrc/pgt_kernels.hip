@@ -96,6 +96,17 @@ struct TreeView {
 // about the same times and the memory controllers see dense write bursts: +3.4 ... +8.6 % across boxes
 // and sizes, results bit for bit the same.  The stage is private to the wave: no barrier.
 // ------------------------------------------------------------------------------------------
+// ONE COLUMN AT A TIME, FEW LOADS IN FLIGHT (round 3).  Until round 3 a wave requested `a` and `b` of 4 (or 8) leaf tiles
+// together: 8 (16) loads in flight from two streams interleaved kibibyte by kibibyte.  The extreme-score build — ONE
+// column, 128 KiB contiguous per tile — reached 84-86 % of the HBM peak where this kernel reached 78-83 %, and the
+// difference turned out to be exactly that: a wave now reads the tile's 64 KiB of `a` (four loads in flight, consumed
+// batch by batch), then its 64 KiB of `b`.  Same leaf sums, same bits.  Interleaved A/B in one process on five boxes
+// (profiles/r03/phased_columns_ab_*.md; % of the HBM peak, old -> new): 10^9 sites 78.4 -> 83.8, 79.7 -> 80.9, 82.9 ->
+// 85.4, 80.6 -> 81.4; 1.25e8 sites (the per-GPU shard of the 8-GPU run) 79.7 -> 82.5, 76.8 -> 83.8, 76.1 -> 83.4, 77.2 ->
+// 82.5; 10^8 sites 75.5 -> 80.4, 75.6 -> 77.7, 78.1 -> 81.6, 77.6 -> 81.7; 5e7 sites 74.3 -> 79.4, 75.0 -> 78.5.  What matters
+// is (i) at least two consecutive batches from the same stream — phases of 16 leaves do as well as 64, phases of one
+// 8-load batch are back at the old rate — and (ii) a SHORT queue: 4 loads in flight beat 8 beat 16 (83.8 / 82.0 / 80.4 at
+// 10^9 sites on one box), 2 and 1 are latency-bound (65 / 40 %); more waves per CU with a shallower stage lose (77 %).
 constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
@@ -136,7 +147,7 @@ struct NodeStage {
         if (++held == STAGE) flush();
     }
 };
-template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>
+template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>  // UNROLL: loads in flight per lane (one column at a time)
 __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv, uint64_t t_begin = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -157,18 +168,25 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
             const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(a + base);
             const double2 *__restrict__ pb = reinterpret_cast<const double2 *>(b + base);
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += UNROLL) {
-                double2 va[UNROLL], vb[UNROLL];
+            for (int j = 0; j < kRadix; j += UNROLL) {  // the tile's 64 KiB of `a` ...
+                double2 v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) v[u] = load16<true>(pa + (j + u) * kWave + lane);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    va[u] = load16<true>(pa + (j + u) * kWave + lane);
-                    vb[u] = load16<true>(pb + (j + u) * kWave + lane);
+                    const double sa = wave_sum(v[u].x + v[u].y);
+                    if (lane == j + u) keep_a = sa;
                 }
+            }
+#pragma unroll 1
+            for (int j = 0; j < kRadix; j += UNROLL) {  // ... then its 64 KiB of `b`
+                double2 v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) v[u] = load16<true>(pb + (j + u) * kWave + lane);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const double sa = wave_sum(va[u].x + va[u].y);
-                    const double sb = wave_sum(vb[u].x + vb[u].y);
-                    if (lane == j + u) { keep_a = sa; keep_b = sb; }
+                    const double sb = wave_sum(v[u].x + v[u].y);
+                    if (lane == j + u) keep_b = sb;
                 }
             }
         } else {
@@ -276,7 +294,18 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
     else if (v == -9.0) acc.nskip += 1;
 }
 
-template <int U = 2>  // leaf tiles per batch: 4*U loads in flight per lane (U = 4 for short inputs, see launch_fst)
+// "The value has arrived; later loads stay behind": an empty asm that reads the register (the compiler places the
+// s_waitcnt for it here) and clobbers memory (no later load is moved above it).
+__device__ __forceinline__ void load_fence(double v) { asm volatile("" ::"v"(v) : "memory"); }
+__device__ __forceinline__ void load_fence(int v) { asm volatile("" ::"v"(v) : "memory"); }
+
+// ONE COLUMN AT A TIME here too (round 3, see fst_build_kernel): per batch of U = 4 leaf tiles the wave requests p1's
+// four kibibytes and waits, p2's and waits, then the two count columns together (eight 8-byte loads).  The per-site
+// value needs all four columns, so the bursts are separated by load fences instead of by consumption.  Interleaved
+// A/B, two boxes (profiles/r03/dxy_ab_*.txt; % of the HBM peak on 24 B/site, the round-2 form -> this one): 10^9 sites
+// 80.0 -> 81.4, 81.7 -> 83.7; 1.25e8 sites 74.5 -> 78.5, 77.1 -> 80.1; 10^8 sites 74.9 -> 79.4, 72.5 -> 75.6.  Waiting after
+// every column (n1 and n2 apart) loses 3-5 points, batches of 8 leaf tiles are no better, batches of 2 are latency-bound.
+template <int U = 4>  // leaf tiles per batch
 __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, const double *__restrict__ p2,
                                                const int32_t *__restrict__ n1, const int32_t *__restrict__ n2,
                                                uint64_t n, int minind, uint64_t n_l2, const TreeView &tv, char *lds_stage) {
@@ -301,12 +330,15 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
                 double2 x1[U], x2[U];
                 int2 k1[U], k2[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
-                    x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
-                    k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
-                    k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
-                }
+                for (int u = 0; u < U; ++u) x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
+                load_fence(x1[U - 1].y);
+#pragma unroll
+                for (int u = 0; u < U; ++u) x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
+                load_fence(x2[U - 1].y);
+#pragma unroll
+                for (int u = 0; u < U; ++u) k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     NodeDxy acc{0.0, 0u, 0u};
@@ -334,25 +366,27 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
     stage.flush();
 }
 
-template <int U = 2>
 __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const double *p2, const int32_t *n1,
                                                         const int32_t *n2, uint64_t n, int minind, uint64_t n_l2,
                                                         TreeView tv) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
-    dxy_build_body<U>(p1, p2, n1, n2, n, minind, n_l2, tv, lds_stage);
+    dxy_build_body<>(p1, p2, n1, n2, n, minind, n_l2, tv, lds_stage);
 }
 
 // BASELINE config 3: dxyWindow + hetWindow (two genotype columns) over one position column and one
 // window table — ONE stream of 26 B/site (p1,p2 f64 + n1,n2 i32 + g1,g2 i8).  The wave that owns level-2
 // tile t of the dxy tree (8192 sites) also owns the SAME 8192 sites of both genotype columns: that is
 // exactly one het work item (8 leaf tiles of 1024 sites, 8 KiB per column).  A genotype column's 8 KiB are
-// requested in ONE burst of eight 16-byte loads per lane — column 0 with the first batch of dxy loads of the
-// tile, column 1 with the batch in the middle — so they are in flight together with the dxy loads and cost no
-// round trip of their own; the byte counts go through the same packed-word popcounts as het_build_body and
+// requested in ONE burst of eight 16-byte loads per lane — column 0 before the first batch of dxy loads of the
+// tile, column 1 before the batch in the middle — and awaited like every other column burst (one column at a
+// time, see dxy_build_body); the byte counts go through the same packed-word popcounts as het_build_body and
 // ONE wave reduction per leaf (nonmissing and nhet packed into one register: both are at most 1024).
-// Measured in one process, interleaved (profiles/r03/fused_ab.txt; % of the HBM peak on 26 B/site at 10^8 /
-// 10^9 sites): 8 dxy loads per batch + bursts 79.6 / 80.8 (this kernel), 8 + one genotype load per batch
-// 78.6 / 80.6, 16 dxy loads per batch 77.4 / 79.0 with either genotype schedule.  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
+// Measured in one process, interleaved (% of the HBM peak on 26 B/site at 10^8 / 10^9 sites).  First
+// (profiles/r03/fused_ab.txt, all columns of a batch requested together): 8 dxy loads per batch + genotype bursts
+// 79.6 / 80.8, 8 + one genotype load per batch 78.6 / 80.6, 16 dxy loads per batch 77.4 / 79.0.  Then
+// (profiles/r03/dxy_ab_second.txt): that best form 76.2 / 80.5 against THIS one — batches of 4 leaf tiles, every
+// column burst awaited, the genotype burst on its own — 76.8 / 81.8 (76.4 -> 76.5 at 1.25e8 sites); the genotype
+// burst travelling with p1's 75.3 / 81.1, batches of 8 leaf tiles 77.3 / 78.8.  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
 // LDS stage beside the tile's dxy row and leave with it (deferred stores, see NodeStage); level 2 of the het
 // trees comes from tree_up_kernel as in the separate build.  Node values and tree layout are those of the
 // separate kernels bit for bit (integer counts; the dxy arithmetic is the same code).
@@ -379,7 +413,7 @@ __device__ __forceinline__ uint32_t het_count_packed(const uint4 &w) {  // nonmi
     return nm | (nh << 16);
 }
 
-template <int U = 2>  // dxy leaf tiles per batch: 4 U loads in flight per lane (+ 8 while a genotype burst is out)
+template <int U = 4>  // dxy leaf tiles per batch
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
     static_assert(kRadix % (2 * U) == 0, "a batch starts in the middle of the tile");
     static_assert((uint64_t)kLeafF64 * kRadix == (uint64_t)kLeafI8 * kHetChunk, "a dxy level-2 tile is one het work item");
@@ -425,17 +459,22 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
                 int2 k1[U], k2[U];
                 uint4 gb[kHetChunk];
                 const bool burst = j == 0 || j == kRadix / 2;  // wave-uniform: genotype column 0 / 1
-                if (burst) {
+                if (burst) {  // the genotype column's 8 KiB: a burst of its own, awaited
 #pragma unroll
                     for (int u = 0; u < kHetChunk; ++u) gb[u] = load16_nt((j == 0 ? h0 : h1) + u * kWave + lane);
+                    load_fence((int)gb[kHetChunk - 1].w);
                 }
+                // the dxy columns one at a time, as in dxy_build_body
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
-                    x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
-                    k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
-                    k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
-                }
+                for (int u = 0; u < U; ++u) x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
+                load_fence(x1[U - 1].y);
+#pragma unroll
+                for (int u = 0; u < U; ++u) x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
+                load_fence(x2[U - 1].y);
+#pragma unroll
+                for (int u = 0; u < U; ++u) k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     NodeDxy acc{0.0, 0u, 0u};
@@ -1533,34 +1572,26 @@ int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_
 // attribute call can fall inside a caller's stream capture.
 int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function attributes are per device
     const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>),
-                            reinterpret_cast<const void *>(fst_build_kernel<kFstStage, 8, true>),
-                            reinterpret_cast<const void *>(dxy_build_kernel<2>), reinterpret_cast<const void *>(dxy_build_kernel<4>),
+                            reinterpret_cast<const void *>(dxy_build_kernel),
                             reinterpret_cast<const void *>(ext_build_kernel<>), reinterpret_cast<const void *>(ext_build_kernel<kExtStage, 8, true>)};
     for (const void *k : staged)
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
                               "hipFuncSetAttribute", err))
             return rc;
-    if (int rc = hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(dxy_het_build_kernel<2>),
+    if (int rc = hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(dxy_het_build_kernel<>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDxyHetStageBytes),
                           "hipFuncSetAttribute", err))
         return rc;
     return PGT_OK;
 }
 
-// The streaming build launch of the fst tree (levels 1 and 2 of `np` pairs).
-// Loads in flight per lane: 8 (UNROLL 4) for long inputs; 16 (UNROLL 8) below ~3e8 sites, where the
-// fixed cost of a launch shows: the last tile of every wave runs latency-bound (16 dependent
-// batches of 8 loads, ~1 us each), with 16 in flight it is half as long.  Measured fit t = t0 +
-// bytes/BW: t0 12.0 -> 9.9 us; +1.5 % at 1e8, +1.8 % at 1.25e8, -0.4 % at 1e9 sites
-// (profiles/r02/size_sweep_variants.md).  The arithmetic order does not depend on it: same bits.
+// The streaming build launch of the fst tree (levels 1 and 2 of `np` pairs): one instantiation at every size (until
+// round 3 short inputs took a form with 16 loads in flight to shorten the latency-bound last tile; with one column at a
+// time the short queue wins at every size, see fst_build_kernel).
 namespace {
 void fst_build_launch(hipStream_t s, const PairCols &cols, uint32_t np, uint64_t n, const TreeLayout &tl, const TreeView &tv) {
     const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks), np);
-    if (tl.count[1] * np <= kFstSmallTiles)
-        hipLaunchKernelGGL((fst_build_kernel<kFstStage, 8, true>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv,
-                           (uint64_t)0);
-    else
-        hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
+    hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
 }
 
 // launch_fst with the build launch as a parameter: the product passes fst_build_launch; tools/pgt_kernels_tuning.hip
@@ -1661,10 +1692,7 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks));
-        if (tl.count[1] <= kFstSmallTiles)  // 16 instead of 8 loads in flight per lane for short inputs (see launch_fst)
-            hipLaunchKernelGGL(dxy_build_kernel<4>, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
-        else
-            hipLaunchKernelGGL(dxy_build_kernel<2>, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
+        hipLaunchKernelGGL(dxy_build_kernel, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(tl, tv, 1, s, err)) return rc;
     }
@@ -1751,8 +1779,7 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
         const uint64_t n_items = het_items(n);  // == td.count[1]: a dxy level-2 tile is one het work item
         DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], tvd, tvh};
         const dim3 grid(build_grid(td.count[1], kFstBuildBlocks));
-        // one instantiation at every size: unlike the single-statistic builds, 16 dxy loads per batch lose here (see the kernel)
-        hipLaunchKernelGGL(dxy_het_build_kernel<2>, grid, dim3(256), kDxyHetStageBytes, s, f);
+        hipLaunchKernelGGL(dxy_het_build_kernel<>, grid, dim3(256), kDxyHetStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;
         if (int rc = launch_upper<NodeHet>(th, tvh, 2, s, err, 1, n_items * kHetChunk)) return rc;  // both genotype trees per launch

@@ -29,6 +29,10 @@ void ext_build_tuned(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t 
         case 4: return launch_ext_variant<8, 8, true>(s, g, n, n_l2, tv, 1024);
         case 5: return launch_ext_variant<8, 2, true>(s, g, n, n_l2, tv, 1024);
         case 6: return launch_ext_variant<8, 8, false>(s, g, n, n_l2, tv, 2048);
+        case 7: return launch_ext_variant<16, 2, true>(s, g, n, n_l2, tv, 512);   // 4 loads in flight (round 3: the short queue)
+        case 8: return launch_ext_variant<16, 4, true>(s, g, n, n_l2, tv, 512);   // 8
+        case 9: return launch_ext_variant<16, 8, true>(s, g, n, n_l2, tv, 512);   // 16
+        case 10: return launch_ext_variant<16, 1, true>(s, g, n, n_l2, tv, 512);  // 2
         default: return ext_build_launch(s, g, n, n_l2, tv);
     }
 }

@@ -3,7 +3,8 @@
 PGT_EXTRA_HIPCC_FLAGS=-DPGT_TUNING_BUILD python -m popgenomicstools_amd.build --force).
 PGT_EXT_VARIANT_NOW selects the variant per call: 0 product (stage 16, 8 waves/CU), 1 direct stores,
 2 stage 8 / 16 waves per CU, 3 stage 4 / 32 waves per CU, 4 product with 16 loads in flight,
-5 product with 4 loads in flight, 6 direct stores with 16 loads in flight.  Rows must be identical."""
+5 product with 4 loads in flight, 6 direct stores with 16 loads in flight; round 3 (the short queue): stage 16 / 8 waves
+per CU with 7: 4, 8: 8, 9: 16, 10: 2 loads in flight.  Rows must be identical.  EXT_VARIANTS=0,7,8 selects."""
 import os
 import sys
 
@@ -33,7 +34,7 @@ def main():
     ctx.set_max_window(int((win_h["hi"] - win_h["lo"]).max()))
     ctx.set_profiling(True)
     tree = torch.empty(ctx.tree_bytes(3, n), dtype=torch.uint8, device=dev)
-    variants = [0, 1, 2, 3, 4, 5, 6]
+    variants = [int(x) for x in os.environ.get("EXT_VARIANTS", "0,1,2,3,4,5,6").split(",")]
     t = {v: [] for v in variants}
     ref = None
     for r in range(reps + 1):
