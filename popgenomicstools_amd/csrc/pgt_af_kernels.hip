@@ -137,7 +137,12 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 }
 
 // ---- BUILD: one wave per level-2 tile (64 pieces of 128 sites = 32 leaf nodes of 256) ---------------
-template <int NP>
+// BURST > 0: one column at a time (pgt_kernels.hip: fst_build_kernel) — per group of BURST pieces each column's BURST
+// kibibytes are requested and awaited in turn.  Taken for TWO populations only (BURST = 4: 77.7 -> 85.3 % of the HBM peak
+// at 10^9 sites, 74.0 -> 75.6 % at 10^8); with 4 and 8 populations the piece-by-piece form below wins (8 populations: 78.2
+// against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt): there the kernel is bound by
+// its node stores and its arithmetic, and 4 x 8 column registers cost the prefetch of the next piece.
+template <int NP, int BURST = 0>
 __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
 
@@ -177,8 +182,44 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
                 }
             }
         };
-        load_tile(cur, 0);
         double vals[V];
+        if constexpr (BURST > 0) {
+            if (full) {
+#pragma unroll 1
+                for (int j0 = 0; j0 < kRadix; j0 += BURST) {
+                    double2 d[NP][BURST];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+                        for (int u = 0; u < BURST; ++u)
+                            d[k][u] = load16<true>(reinterpret_cast<const double2 *>(cols.f[k] + base) + (j0 + u) * kWave + lane);
+                        if (k + 1 < NP) load_fence(d[k][BURST - 1].y);
+                    }
+#pragma unroll
+                    for (int u = 0; u < BURST; ++u) {
+                        const int j = j0 + u;
+                        if ((u & (kAfPieces - 1)) == 0) {
+#pragma unroll
+                            for (int v = 0; v < V; ++v) vals[v] = 0.0;
+                        }
+                        double fx[NP], fy[NP];
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) { fx[k] = d[k][u].x; fy[k] = d[k][u].y; }
+                        af_accumulate<NP>(vals, fx);
+                        af_accumulate<NP>(vals, fy);
+                        if ((u & (kAfPieces - 1)) == kAfPieces - 1) {
+                            rs_steps<V, 0>(vals, lane);
+                            if (my >= 0) {
+                                stage[(j / kAfPieces) * V + my] = vals[0];
+                                l2acc += vals[0];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (BURST == 0 || !full) {
+        load_tile(cur, 0);
 #pragma unroll kAfPieces
         for (int j = 0; j < kRadix; ++j) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
             double2 nxt[NP];
@@ -201,6 +242,7 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
+        }
         }
         if (my >= 0) *af_node<V>(tv, 1, my, t) = l2acc;  // the level-2 node: V consecutive doubles, one 8*V-byte run
         // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
@@ -341,7 +383,7 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
         uint64_t blocks = (waves + 3) / 4;
         constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x 32 nodes x V doubles
-        hipLaunchKernelGGL((af_build_kernel<NP>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        hipLaunchKernelGGL((af_build_kernel<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
         for (int k = 2; k < tv.n_levels; ++k) {
             uint64_t b = (tl.count[k] + 3) / 4;
@@ -366,7 +408,7 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
 namespace {
 template <int NP>
 void af_allow_lds() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP, (NP == 2 ? 4 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double)));
 }
 }  // namespace

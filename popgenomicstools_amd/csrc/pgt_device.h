@@ -97,6 +97,12 @@ __device__ __forceinline__ uint4 load16_nt(const uint4 *p) {
     v.w = __builtin_nontemporal_load(&p->w);
     return v;
 }
+// "The value has arrived; later loads stay behind": an empty asm that reads the register (the compiler places the
+// s_waitcnt for it here) and clobbers memory (no later load is moved above it).  Separates the column bursts of the
+// build kernels: one column at a time, a short queue (pgt_kernels.hip: fst_build_kernel).
+__device__ __forceinline__ void load_fence(double v) { asm volatile("" ::"v"(v) : "memory"); }
+__device__ __forceinline__ void load_fence(int v) { asm volatile("" ::"v"(v) : "memory"); }
+
 __device__ __forceinline__ int2 load8_nt(const int2 *p) {
     int2 v;
     v.x = __builtin_nontemporal_load(&p->x);

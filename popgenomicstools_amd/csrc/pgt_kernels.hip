@@ -294,10 +294,6 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
     else if (v == -9.0) acc.nskip += 1;
 }
 
-// "The value has arrived; later loads stay behind": an empty asm that reads the register (the compiler places the
-// s_waitcnt for it here) and clobbers memory (no later load is moved above it).
-__device__ __forceinline__ void load_fence(double v) { asm volatile("" ::"v"(v) : "memory"); }
-__device__ __forceinline__ void load_fence(int v) { asm volatile("" ::"v"(v) : "memory"); }
 
 // ONE COLUMN AT A TIME here too (round 3, see fst_build_kernel): per batch of U = 4 leaf tiles the wave requests p1's
 // four kibibytes and waits, p2's and waits, then the two count columns together (eight 8-byte loads).  The per-site
@@ -384,9 +380,10 @@ __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const 
 // Measured in one process, interleaved (% of the HBM peak on 26 B/site at 10^8 / 10^9 sites).  First
 // (profiles/r03/fused_ab.txt, all columns of a batch requested together): 8 dxy loads per batch + genotype bursts
 // 79.6 / 80.8, 8 + one genotype load per batch 78.6 / 80.6, 16 dxy loads per batch 77.4 / 79.0.  Then
-// (profiles/r03/dxy_ab_second.txt): that best form 76.2 / 80.5 against THIS one — batches of 4 leaf tiles, every
-// column burst awaited, the genotype burst on its own — 76.8 / 81.8 (76.4 -> 76.5 at 1.25e8 sites); the genotype
-// burst travelling with p1's 75.3 / 81.1, batches of 8 leaf tiles 77.3 / 78.8.  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
+// (profiles/r03/dxy_ab_second.txt, fused_ab_awaited_box*.txt; three boxes): that best form 76.2 / 80.5, 77.3 / 76.9,
+// 76.0 / 77.1 against THIS one — batches of 4 leaf tiles, every column burst awaited, the genotype burst on its own —
+// 76.8 / 81.8, 76.8 / 78.2, 75.9 / 78.4: +1.3 points at 10^9 sites on every box, a tie at 10^8 and 1.25e8; the genotype
+// burst travelling with p1's 75.3 / 81.1, batches of 8 leaf tiles 77.3 / 78.8, batches of 2 awaited 62 / 65.  The 2 x 8 level-1 het nodes of a tile are parked in the wave's
 // LDS stage beside the tile's dxy row and leave with it (deferred stores, see NodeStage); level 2 of the het
 // trees comes from tree_up_kernel as in the separate build.  Node values and tree layout are those of the
 // separate kernels bit for bit (integer counts; the dxy arithmetic is the same code).
