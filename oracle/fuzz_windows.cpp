@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pgtwin.h"
+#include "pgt_internal.h"
 #include "window_oracle.h"
 
 static int fail(const char *what, int trial) {
@@ -24,6 +25,22 @@ int main(int argc, char **argv) {
     const int trials = argc > 1 ? std::atoi(argv[1]) : 2000;
     std::mt19937_64 rng(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 12345);
     auto U = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
+    {   // the query strategy follows the two hints alone (pgt_internal.h): boundaries of the group / sliding / per-window choice
+        using namespace pgt;
+        auto H = [](uint64_t max_window, uint64_t step, uint64_t typical = 0) { Hints h; h.max_window = max_window; h.window_step = step; h.typical_window = typical; return h; };
+        const bool ok =
+            !group_query(H(50000, 0), kLeafF64) && slide_group(0) == 1 &&                      // unknown step: one wave per window
+            group_query(H(50000, 1), kLeafF64) && group_query(H(50000, 1024), kLeafF64) &&   // steps 1 .. 1024, windows >= 2 level-2 tiles
+            !group_query(H(50000, 1025), kLeafF64) && slide_group(1025) == 1 &&
+            group_query(H(16384, 100), kLeafF64) && !group_query(H(16383, 100), kLeafF64) &&
+            !group_query(H(0, 100), kLeafF64) &&                                               // unknown window length: not the group query
+            !group_query(H(50000, 100), kLeafI8) && group_query(H(131072, 100), kLeafI8) &&   // the genotype tree: 65536-site level-2 tiles
+            !group_query(H(1000000, 100, 3000), kLeafF64) && group_query(H(1000000, 100, 20000), kLeafF64) &&  // the typical length decides where it is known
+            slide_group(1) == 64 && slide_group(2) == 64 && slide_group(3) == 43 && slide_group(32) == 5 && slide_group(33) == 1 &&
+            group_edge_scans(H(50000, 64)) == 1 && group_edge_scans(H(50000, 65)) == 0 &&
+            group_size(64 * 8192) == 64 && group_size(64 * 8192 - 1) == 32 && group_size(32 * 8192 - 1) == 16 && group_size(0) == 16;
+        if (!ok) return fail("query strategy boundaries", 0);
+    }
     size_t windows = 0;
     for (int t = 0; t < trials; ++t) {
         const uint32_t W = (uint32_t)U(1, 40), S = (uint32_t)U(1, (int)W);
