@@ -659,6 +659,7 @@ struct TabHints {
     pgt::Hints saved;
     TabHints(pgt_ctx *c, const pgt_wintab *t) : ctx(c), saved(c->hints) {
         c->hints.max_window = t->W;
+        c->hints.typical_window = 0;  // W stands for the typical length
         c->hints.window_step = t->S;
     }
     ~TabHints() { ctx->hints = saved; }
