@@ -132,3 +132,19 @@ def dxy_ref_cases(tmp_path, plain_text=False):
         opt["maf1"], opt["maf2"] = argv[-2], argv[-1]
         out.append((c, argv, opt))
     return out
+
+
+def small_step_cases():
+    """tests/golden/ref_small_step.json: reference-made runs with S << W whose inputs are regenerated from a seed
+    (tests/golden/make_golden.py: small_step_input).  Yields (case, columns dict, fst text, het text) per distinct input."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    cases = load_golden("ref_small_step.json")["cases"]
+    seen = {}
+    for c in cases:
+        key = (c["seed"], c["n"], c["n_chr"])
+        if key not in seen:
+            chr_ids, pos, a, b, g, fst, het = make_golden.small_step_input(*key)
+            seen[key] = {"chr_ids": chr_ids, "pos": pos, "a": a, "b": b, "g": g, "fst": fst, "het": het}
+        yield c, seen[key]

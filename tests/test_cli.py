@@ -121,6 +121,22 @@ def test_fst_het_cli_against_reference_goldens(hosts, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_small_step_reference_goldens(hosts, tmp_path):
+    """The hosts on the seeded tables of tests/golden/ref_small_step.json (S << W; reference-made): hetWindow's stdout has the
+    SHA-256 of the reference's (byte-identical over all rows), fstWindow's rows agree with every k-th reference row."""
+    import hashlib
+    for c, cols in helpers.small_step_cases():
+        f = tmp_path / "in.txt"
+        f.write_text(cols["fst"] if c["tool"] == "fstWindow" else cols["het"])
+        r = run([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])])
+        assert r.returncode == 0 and len(r.stdout.splitlines()) == c["n_rows"], (c["tool"], c["W"], c["S"], r.stderr)
+        if c["tool"] == "hetWindow":
+            assert hashlib.sha256(r.stdout.encode()).hexdigest() == c["stdout_sha256"]
+        else:
+            tsv_equal("\n".join(r.stdout.splitlines()[:: c["every"]]) + "\n", "\n".join(c["rows"]) + "\n", 4)
+
+
+@pytest.mark.gpu
 def test_fst_cli_config1(hosts, tmp_path, oracle):
     import synth
     g = helpers.load_golden("ref_config1.json")

@@ -1111,6 +1111,27 @@ def test_group_query_vs_oracle(pgt, ctx, oracle, W, S, n):
         check_dxy(pgt, ctx, oracle, chr_ids, pos, p1, p2, n1, n2, W, S, 5, 1, 0)
 
 
+def test_small_step_reference_goldens(pgt, ctx):
+    """The C-ABI rows against runs of the UNMODIFIED reference tools with S << W (tests/golden/ref_small_step.json: seeded
+    tables of up to 4x10^5 sites, windows of 3000 .. 140000 sites, steps 1 .. 2500 — the group, sliding and per-window
+    queries): the number of rows, and every k-th row of the reference's stdout (labels, coordinates, counts exact; the
+    ratio within 1e-9 + the 6-digit print)."""
+    n = 0
+    for c, cols in helpers.small_step_cases():
+        names = [f"chr{i + 1}" for i in range(int(cols["chr_ids"].max()) + 1)]
+        if c["tool"] == "fstWindow":
+            res = pgt.fst_window(cols["chr_ids"], cols["pos"], cols["a"], cols["b"], c["W"], c["S"], ctx=ctx)
+            stat, cnt = "fst", "n"
+        else:
+            res = pgt.het_window(cols["chr_ids"], cols["pos"], cols["g"], c["W"], c["S"], ctx=ctx)
+            stat, cnt = "h", "nonmissing"
+        assert res.rows.size == c["n_rows"], (c["tool"], c["W"], c["S"])
+        k = c["every"]
+        helpers.assert_rows_match_tsv(names, res.win[::k], res.rows[::k], stat, cnt, helpers.parse_tsv("\n".join(c["rows"])))
+        n += 1
+    assert n == 16
+
+
 def test_sliding_query_agrees_with_per_window_query_and_is_shard_independent(pgt, ctx):
     """Device API: with the step hint (sliding) and without (one wave per window) the integer columns
     are identical and the sums agree to 1e-9; het rows are bitwise equal (integer sums); and the sliding

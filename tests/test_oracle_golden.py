@@ -64,6 +64,23 @@ def test_config1_golden(oracle, tmp_path):
     assert len(g["runs"][0]["stdout"].splitlines()) == 19  # Q2: the 20th chromosome is dropped
 
 
+def test_small_step_goldens(oracle, tmp_path):
+    """S << W (`fstWindow file 50000 100`: the reference re-sums W sites per window, fstWindow.cpp:80-83,95-99), tables too
+    large to commit: the input is regenerated from its seed (hash checked) and the oracle's stdout must have the SHA-256
+    of the reference's, i.e. be byte-identical over all rows (16 runs, up to 4x10^5 sites, 40 000 rows)."""
+    import hashlib
+    n = 0
+    for c, cols in helpers.small_step_cases():
+        text = cols["fst"] if c["tool"] == "fstWindow" else cols["het"]
+        assert hashlib.sha256(text.encode()).hexdigest() == c["input_sha256"]
+        rc, out = _run_text(oracle, c["tool"], text, c["W"], c["S"], tmp_path)
+        assert rc == 0 and c["rc"] == 0
+        assert len(out.splitlines()) == c["n_rows"] and out.splitlines()[:: c["every"]] == c["rows"]
+        assert hashlib.sha256(out.encode()).hexdigest() == c["stdout_sha256"], (c["tool"], c["W"], c["S"])
+        n += 1
+    assert n == 16
+
+
 def _write_maf(path, header, rows):
     with open(path, "w") as f:
         f.write(header + "\n")
