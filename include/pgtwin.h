@@ -283,6 +283,8 @@ int pgt_rowbuf_fill(pgt_ctx *ctx, void *dev_ptr, size_t bytes, uint64_t seed, vo
  * contexts — the same device, or two devices (peer copy where the link allows it, staged by the runtime otherwise);
  * it is synchronous and may be called from the thread of either context. */
 int pgt_dev_alloc(pgt_ctx *ctx, size_t bytes, void **dev_ptr);
+/* free and total memory of ctx's device in bytes (the hosts decide with it whether a table must be reduced in passes) */
+int pgt_dev_memory(pgt_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr);
 int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src, size_t bytes);
 

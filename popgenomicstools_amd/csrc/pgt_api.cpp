@@ -451,6 +451,15 @@ int pgt_dev_alloc(pgt_ctx *ctx, size_t bytes, void **dev_ptr) {
     return hip_check(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16), "pgt_dev_alloc: hipMalloc");
 }
 
+int pgt_dev_memory(pgt_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    PGT_USE_DEVICE(ctx);
+    size_t f = 0, t = 0;
+    if (int rc = hip_check(ctx, hipMemGetInfo(&f, &t), "pgt_dev_memory: hipMemGetInfo")) return rc;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return PGT_OK;
+}
+
 int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr) {
     PGT_USE_DEVICE(ctx);
     if (!dev_ptr) return PGT_OK;

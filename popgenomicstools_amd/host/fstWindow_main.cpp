@@ -60,8 +60,34 @@ int main(int argc, char **argv) {
     } else {
         if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
         const char *what = "fstWindow: cannot parse 'chr pos a b'";
+        static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64};
+        if (const uint64_t resident = resident_limit(text.size(), 4 + 8 + 8, [&] { return device.get(); })) {
+            // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
+            const size_t row_bytes_max = 80;
+            reduce_in_passes<pgt_fst_row>(
+                device.get(), text.begin(), text.end(), W, S, resident, runs, timer,
+                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_fst_row *out) {
+                    DeviceTable piece;
+                    Runs piece_runs;
+                    if (ingest_on_device(c, pb, pe, spec, 4, what, argv[1], first_row + 1, piece, piece_runs)) {
+                        if (piece.n != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
+                        check(pgt_fst_reduce_cols(c, piece.col<uint32_t>(1), piece.col<double>(2), piece.col<double>(3), piece.n, w, nw, out,
+                                                  nw * sizeof(*out)), c);
+                    } else {
+                        decltype(tab) t;
+                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
+                        if (k != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
+                        check(pgt_fst_reduce(c, t.pos.data(), t.a.data(), t.b.data(), k, w, nw, out), c);
+                    }
+                },
+                [&](const pgt_fst_row *r, size_t nw, const pgt_win *w) {
+                    write_rows(nw, longest_name(runs) + row_bytes_max, [&](size_t i, char *o) {
+                        return put_row(o, runs.name[w[i].label_run], {r[i].start, r[i].end, r[i].mid}, r[i].fst, {r[i].n});
+                    });
+                });
+            finish(timer);
+        }
         if (gpu_ingest_wanted(text.size())) {
-            static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64};
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
             if (multi) {

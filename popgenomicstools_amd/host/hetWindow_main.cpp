@@ -64,8 +64,32 @@ int main(int argc, char **argv) {
     } else {
         if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
         const char *what = "hetWindow: cannot parse 'chr pos genotype'";
+        static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8};
+        if (const uint64_t resident = resident_limit(text.size(), 4 + 1, [&] { return device.get(); })) {
+            // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
+            reduce_in_passes<pgt_het_row>(
+                device.get(), text.begin(), text.end(), W, S, resident, runs, timer,
+                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_het_row *out) {
+                    DeviceTable piece;
+                    Runs piece_runs;
+                    if (ingest_on_device(c, pb, pe, spec, 3, what, argv[1], first_row + 1, piece, piece_runs)) {
+                        if (piece.n != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
+                        check(pgt_het_reduce_cols(c, piece.col<uint32_t>(1), piece.col<int8_t>(2), piece.n, w, nw, out, nw * sizeof(*out)), c);
+                    } else {
+                        decltype(tab) t;
+                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
+                        if (k != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
+                        check(pgt_het_reduce(c, t.pos.data(), t.g.data(), k, w, nw, out), c);
+                    }
+                },
+                [&](const pgt_het_row *r, size_t nw, const pgt_win *w) {
+                    write_rows(nw, longest_name(runs) + 80, [&](size_t i, char *o) {
+                        return put_row(o, runs.name[w[i].label_run], {r[i].start, r[i].end, r[i].mid}, r[i].h, {r[i].nonmissing});
+                    });
+                });
+            finish(timer);
+        }
         if (gpu_ingest_wanted(text.size())) {
-            static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8};
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
             if (multi) {

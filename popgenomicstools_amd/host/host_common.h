@@ -966,6 +966,127 @@ void reduce_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, ui
     for (auto &t : th) t.join();
 }
 
+// ---- a table larger than the GPU: reduced in PASSES (PGT_MAX_RESIDENT_SITES, or by itself when the text would not fit) -----
+// The reference streams with O(W) memory (fstWindow.cpp:111-113); the paths above hold one whole input on the GPU.  Here
+// a first, cheap pass over the text on the host threads finds the chromosome runs and the byte position of every
+// 65536th row (no number is converted); the window table is built from the runs, cut by pgt_plan_shards into blocks of
+// at most the resident limit, and every block is one pass: the text of ITS rows [site_lo, site_hi) (+ the halo of one window
+// that pgt_plan_shards adds; block starts are multiples of 65536 rows, so they are marked) is parsed on the GPU, the block's
+// windows are reduced and its rows are printed before the next pass starts — the output streams as the reference's does.
+// GPU memory per pass: the text and the columns of one block.  A bad line is reported when its pass reaches it (rows of
+// earlier passes are out by then — the reference would have printed them too).  First listed device only.
+constexpr uint64_t kMarkEvery = 65536;  // rows between two byte marks = the smallest shard alignment of pgt_plan_shards
+
+// runs of chromosome names, the number of rows and the row marks of [b,e); stops at the first blank line like the parsers
+inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std::vector<const char *> &mark, const char **data_end) {
+    int T = host_threads();
+    if ((size_t)(e - b) < (1u << 20)) T = 1;
+    const std::vector<const char *> cut = cut_at_lines(b, e, (size_t)T);
+    std::vector<size_t> lines(T, 0), off(T + 1, 0);
+    auto run_all = [&](auto &&fn) {
+        if (T == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    run_all([&](int t) {
+        size_t k = (size_t)std::count(cut[t], cut[t + 1], '\n');
+        if (cut[t + 1] > cut[t] && cut[t + 1][-1] != '\n') ++k;  // last line without newline
+        lines[t] = k;
+    });
+    for (int t = 0; t < T; ++t) off[t + 1] = off[t] + lines[t];
+    mark.assign(off[T] / kMarkEvery + 2, nullptr);
+    struct Result { size_t rows = 0; bool stopped = false; const char *end = nullptr; Runs runs; };
+    std::vector<Result> res(T);
+    run_all([&](int t) {
+        Result &r = res[t];
+        Cursor c{cut[t], cut[t + 1]};
+        size_t row = off[t];
+        while (c.p < c.end) {
+            const char *line = c.p;
+            c.skip_blank();
+            if (c.at_eol()) { r.stopped = true; r.end = line; break; }
+            if (row % kMarkEvery == 0) mark[row / kMarkEvery] = line;
+            const Tok chr = c.token();
+            r.runs.add(chr.first, chr.second);
+            ++row;
+            c.next_line();
+        }
+        if (!r.stopped) r.end = cut[t + 1];
+        r.rows = row - off[t];
+    });
+    size_t n = 0;
+    *data_end = b;
+    for (int t = 0; t < T; ++t) {
+        runs.append(res[t].runs);
+        n = off[t] + res[t].rows;
+        *data_end = res[t].end;
+        if (res[t].stopped) break;
+    }
+    mark.resize(n / kMarkEvery + 2);
+    mark[(n + kMarkEvery - 1) / kMarkEvery] = *data_end;  // the mark behind the last row
+    return n;
+}
+
+// 0: the whole input fits (the usual paths); else the largest number of sites one pass may hold.
+// PGT_MAX_RESIDENT_SITES=<n> forces passes (tests, or a GPU shared with other work).
+template <class GetCtx>
+inline uint64_t resident_limit(size_t text_bytes, size_t bytes_per_site_on_gpu, GetCtx &&get_ctx) {
+    if (const char *e = std::getenv("PGT_MAX_RESIDENT_SITES")) {
+        const long long v = std::atoll(e);
+        return v > 0 ? (uint64_t)v : 0;
+    }
+    if (text_bytes < ((size_t)8 << 30)) return 0;  // far below any MI355X: do not even ask
+    size_t free_b = 0, total_b = 0;
+    pgt_ctx *ctx = get_ctx();
+    check(pgt_dev_memory(ctx, &free_b, &total_b), ctx);
+    // one pass holds its text (~text_bytes / sites per site) and its columns; keep a fifth of the memory free
+    const double need = (double)text_bytes * 1.25 + (double)text_bytes / 24.0 * (double)bytes_per_site_on_gpu;  // >= 24 B of text per site
+    if (need < 0.8 * (double)free_b) return 0;
+    const double per_site = 40.0 * 1.25 + (double)bytes_per_site_on_gpu;  // ~40 B of text per site at most for these tables
+    return (uint64_t)(0.6 * (double)free_b / per_site);
+}
+
+// The passes.  parse_and_reduce(ctx, piece_begin, piece_end, first_row /*global*/, rows_in_piece, win /*rebased*/, n_win, out)
+// parses the piece (device parser; host parser where the device refuses) and reduces the block's windows;
+// print(rows, n_win, win /*the block's entries of the global table: label_run*/) writes them.  Host memory: the mapped
+// text and the window table (24 bytes per window).
+template <class Row, class ParseReduce, class Print>
+void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, uint32_t S, uint64_t max_resident, Runs &runs,
+                      PhaseTimer &timer, ParseReduce parse_and_reduce, Print print) {
+    std::vector<const char *> mark;
+    const char *data_end = b;
+    const size_t n = scan_runs_and_marks(b, e, runs, mark, &data_end);
+    timer.lap("scan runs");
+    size_t n_win = 0;
+    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+    if (n_win == 0) return;
+    std::vector<pgt_win> win(n_win);
+    check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+    const uint64_t per_pass = std::max<uint64_t>(max_resident, 2 * (uint64_t)W + 2 * kMarkEvery);
+    const uint32_t passes = (uint32_t)std::min<uint64_t>((n + per_pass - 1) / per_pass + 1, 1u << 20);
+    std::vector<pgt_shard> shard(passes);
+    check(pgt_plan_shards(win.data(), n_win, passes, shard.data()), nullptr);
+    timer.lap("window table");
+    set_site_hints(ctx, W, S);
+    std::vector<Row> rows;
+    for (uint32_t p = 0; p < passes; ++p) {
+        const pgt_shard sh = shard[p];
+        const size_t n_local = (size_t)(sh.win_end - sh.win_begin);
+        if (n_local == 0) continue;
+        if (sh.site_lo % kMarkEvery != 0) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
+        const uint64_t hi_mark = std::min<uint64_t>((sh.site_hi + kMarkEvery - 1) / kMarkEvery, (n + kMarkEvery - 1) / kMarkEvery);
+        const char *pb = mark[sh.site_lo / kMarkEvery], *pe = mark[hi_mark];
+        const uint64_t rows_in_piece = std::min<uint64_t>(hi_mark * kMarkEvery, n) - sh.site_lo;
+        std::vector<pgt_win> local(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end);
+        for (pgt_win &w : local) { w.lo -= sh.site_lo; w.hi -= sh.site_lo; }
+        rows.resize(n_local);
+        parse_and_reduce(ctx, pb, pe, sh.site_lo, rows_in_piece, local.data(), n_local, rows.data());
+        print(rows.data(), n_local, win.data() + sh.win_begin);
+    }
+    timer.lap("passes");
+}
+
 // Window size / step size as fstWindow.cpp:51-64 reads them (atoi); zero, negative or
 // non-numeric values are refused.  The reference only warns for a bad step and then crashes
 // (SURVEY.md §4 Q9); a step larger than the window crashes it too.  Here all of these exit 255.

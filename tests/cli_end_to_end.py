@@ -88,6 +88,12 @@ def main():
             same, t_ref_s, sp = "n/a", "n/a", "n/a"
         phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_new.stderr.decode().splitlines() if "pgt-host" in ln)
         print(f"| {tool} | {t_ref_s} | {t_new:.2f} | {sp} | {len(r_new.stdout.splitlines())} | {same} | {phases} |")
+        # the same run in passes (PGT_MAX_RESIDENT_SITES): how an input larger than the GPU's memory is reduced — an eighth of
+        # the table resident at a time, rows printed block by block
+        t_p, r_p = wall([os.path.join(BIN, tool), path, "50000", "10000"], dict(env, PGT_MAX_RESIDENT_SITES=str(max(n // 8, 1))))
+        phases = "; ".join(ln.replace("[pgt-host]", "").strip() for ln in r_p.stderr.decode().splitlines() if "pgt-host" in ln)
+        print(f"| {tool}, in passes of <= {max(n // 8, 1):.3g} resident sites (PGT_MAX_RESIDENT_SITES) | {t_ref_s} | {t_p:.2f} | "
+              f"{(t_ref / t_p if ref else 0):.1f}x | {len(r_p.stdout.splitlines())} | {r_p.stdout == r_new.stdout} | {phases} |")
         # the same run with the binary column cache (PGT_COLUMN_CACHE): first run writes it, second maps it
         cdir = os.path.join(d, "cache_" + tool)
         os.mkdir(cdir)

@@ -9,7 +9,8 @@
 //   4. Text on gzip input: a bgzf file (block-parallel inflate), a plain gzip file and a bgzf file followed by a
 //      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused;
 //   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
-//      per piece and stitched with Runs::add are the runs of the whole text.
+//      per piece and stitched with Runs::add are the runs of the whole text;
+//   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks.
 #include <dirent.h>
 
 #include <cinttypes>
@@ -340,6 +341,34 @@ int main(int argc, char **argv) {
                     stitched.add(piece.name[r].data(), piece.name[r].data() + piece.name[r].size(), piece.len[r]);
             }
             CHECK(stitched.name == whole.name && stitched.len == whole.len);
+        }
+    }
+    {   // 6. the first scan of the passes mode (scan_runs_and_marks): rows, runs, the end of the data and a mark at every 65536th row
+        for (int trial = 0; trial < 6; ++trial) {
+            std::string text;
+            Runs whole;
+            const size_t n_lines = trial == 0 ? 0 : trial == 1 ? 65536 : trial == 2 ? 131072 : 100000 + rng() % 200000;
+            const size_t blank_at = trial >= 4 ? n_lines / 2 + rng() % 1000 : ~(size_t)0;  // the parsers stop at the first blank line
+            std::vector<size_t> line_start;
+            size_t rows = 0, chr = 0;
+            for (size_t i = 0; i < n_lines; ++i) {
+                if (i == blank_at) { text += " \t\n"; continue; }
+                if (rng() % 30011 == 0) ++chr;
+                const std::string name = "scaffold_" + std::to_string(chr);
+                if (i < blank_at) { whole.add(name.data(), name.data() + name.size()); line_start.push_back(text.size()); ++rows; }
+                text += name + "\t" + std::to_string(i + 1) + "\t0." + std::to_string(rng() % 1000) + "\t0.5\n";
+            }
+            if (n_lines && trial == 3) text.pop_back();  // last line without newline
+            const char *b = text.data(), *e = b + text.size(), *data_end = nullptr;
+            Runs runs;
+            std::vector<const char *> mark;
+            const size_t n = scan_runs_and_marks(b, e, runs, mark, &data_end);
+            CHECK(n == rows);
+            CHECK(runs.name == whole.name && runs.len == whole.len);
+            CHECK(data_end == (blank_at < n_lines ? b + line_start.back() + (std::strchr(b + line_start.back(), '\n') - (b + line_start.back())) + 1 : e));
+            CHECK(mark.size() >= (n + kMarkEvery - 1) / kMarkEvery + 1);
+            for (size_t k = 0; k * kMarkEvery < n; ++k) CHECK(mark[k] == b + line_start[k * kMarkEvery]);
+            CHECK(mark[(n + kMarkEvery - 1) / kMarkEvery] == data_end);
         }
     }
     std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);

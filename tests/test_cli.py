@@ -542,6 +542,88 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
+    """PGT_MAX_RESIDENT_SITES=<n>: the table is reduced block by block (first scan of the text on the host for runs and
+    row marks, then per block: text of its rows -> GPU parser -> reduce -> print), as for an input larger than the GPU's
+    memory.  stdout and the exit code must be those of the resident run, byte for byte: reference-made goldens, a
+    blank-line stop, a bad line (global line number; the rows of earlier blocks are out by then), and 3 * 10^6-line tables
+    in 7 uneven chromosomes for fstWindow (per-window, group and sliding query) and hetWindow at several limits."""
+    import synth
+
+    def passes(cmd, limit, **env):
+        return run(cmd, env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit), **env))
+
+    for c in helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::3]:
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        r = passes([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], 1)
+        assert r.returncode == 0, r.stderr[-300:]
+        tsv_equal(r.stdout, c["stdout"], 4)
+    import hashlib
+    for c, cols in helpers.small_step_cases():  # S << W, reference-made
+        f = tmp_path / "in.txt"
+        f.write_text(cols["fst"] if c["tool"] == "fstWindow" else cols["het"])
+        r = passes([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], 1)
+        assert r.returncode == 0 and len(r.stdout.splitlines()) == c["n_rows"], (c["tool"], c["W"], c["S"], r.stderr)
+        if c["tool"] == "hetWindow":
+            assert hashlib.sha256(r.stdout.encode()).hexdigest() == c["stdout_sha256"]
+        else:
+            tsv_equal("\n".join(r.stdout.splitlines()[:: c["every"]]) + "\n", "\n".join(c["rows"]) + "\n", 4)
+    rng = np.random.default_rng(77)
+    n = 3_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 7, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    big = tmp_path / "big.fst.txt"
+    oracle.write_fst_text(str(big), chr_ids, pos, a, b)
+    for W, S in ((50_000, 10_000), (50_000, 100), (700, 5), (131_072, 65_536), (1, 1)):
+        if S == 1:
+            small = tmp_path / "small.fst.txt"
+            small.write_text("".join(big.read_text().splitlines(True)[:400_000]))
+            cmd = [hosts["fstWindow"], str(small), str(W), str(S)]
+        else:
+            cmd = [hosts["fstWindow"], str(big), str(W), str(S)]
+        one = run(cmd)
+        assert one.returncode == 0 and one.stdout
+        timed = passes(cmd, 300_000, PGT_HOST_TIMING="1")  # the phases say which path ran
+        assert "scan runs" in timed.stderr and "passes" in timed.stderr and timed.stdout == one.stdout
+        assert "scan runs" not in run(cmd, env=dict(os.environ, PGT_HOST_TIMING="1")).stderr
+        for limit in (1, 300_000, 1_000_000, 2_999_999, 10**9):
+            r = passes(cmd, limit)
+            assert (r.returncode, r.stderr) == (0, one.stderr), (W, S, limit, r.stderr[-300:])
+            assert r.stdout == one.stdout, (W, S, limit)
+    # the data ends at a blank line in a later block; then a bad line there
+    lines = big.read_text().splitlines(True)
+    stop = tmp_path / "stop.fst.txt"
+    stop.write_text("".join(lines[:2_100_000]) + "  \n" + "".join(lines[2_100_000:]))
+    cmd = [hosts["fstWindow"], str(stop), "50000", "10000"]
+    one = run(cmd)
+    r = passes(cmd, 300_000)
+    assert one.returncode == 0 and (r.returncode, r.stdout) == (0, one.stdout)
+    stop.write_text("".join(lines[:2_100_000]) + lines[2_100_000].split("\t")[0] + "\t5\tzero\t1\n" + "".join(lines[2_100_001:]))
+    one = run(cmd)
+    r = passes(cmd, 300_000)
+    assert one.returncode == 255 and "line 2100001 " in one.stderr and one.stdout == ""
+    assert r.returncode == 255 and r.stderr == one.stderr
+    full = run([hosts["fstWindow"], str(big), "50000", "10000"]).stdout
+    assert r.stdout and full.startswith(r.stdout) and len(r.stdout) < len(full)  # what was printed before the bad block is right
+    os.unlink(stop)
+    os.unlink(big)
+    g = synth.het_column(rng, n)
+    bigh = tmp_path / "big.het.txt"
+    with open(bigh, "w") as fh:
+        for lo in range(0, n, 1_000_000):
+            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    for W, S in ((50_000, 10_000), (200_000, 64), (1000, 1000)):
+        cmd = [hosts["hetWindow"], str(bigh), str(W), str(S)]
+        one = run(cmd)
+        assert one.returncode == 0 and one.stdout
+        for limit in (1, 500_000):
+            r = passes(cmd, limit)
+            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, limit, r.stderr[-300:])
+
+
+@pytest.mark.gpu
 def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
     """Where oracle/_ref holds the compiled, unmodified reference tools (this container, and the GPU box, which
     receives them with the snapshot): fresh random inputs — other seeds than the committed goldens — through the
