@@ -229,6 +229,14 @@ int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites);
  * them — under one pair of hints, rows are bitwise independent of which windows share a wave and of the number of
  * GPUs.  The host-buffer entry points derive the hint from the table while it is unset. */
 int pgt_set_window_step(pgt_ctx *ctx, uint64_t step_sites);
+/* Tables whose windows vary in length (dxyWindow's base-pair windows): the typical (median) window length, which then
+ * decides between the strategies instead of the longest.  Call it AFTER pgt_set_max_window (which resets it to "the same").
+ * pgt_table_hints gives the three values exactly as the host-buffer entry points derive them from a table while the hints
+ * are unset: a caller that reduces SLICES of one table on several GPUs sets them on every context, so that every slice
+ * is reduced as the whole table would be (rows bitwise independent of the slicing).  The step comes back as UINT64_MAX
+ * where the table has no typical positive step (0 would mean "unknown" and let every slice estimate its own). */
+int pgt_set_typical_window(pgt_ctx *ctx, uint64_t typical_sites);
+int pgt_table_hints(const pgt_win *win, uint64_t n_win, uint64_t *max_window, uint64_t *typical_window, uint64_t *window_step);
 
 /* ---- per-kernel timing (HIP events on the launch stream; for bench.py's roofline) ------- */
 /* When enabled, the *_dev entry points bracket the tree-build kernel and the window-query

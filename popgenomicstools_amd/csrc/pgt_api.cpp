@@ -61,33 +61,44 @@ struct DevBuf {
 };
 
 // RAII: the host-buffer entry points know the table, so they set the max-window hint themselves
+// The three hints of a host table (pgt_table_hints): longest window; typical (median) length and typical step = median
+// distance between consecutive window starts, both over a sample from the middle of the table (chromosome boundaries and
+// the Q1 carry make a few distances irregular).  The typical length decides whether the group query fits, not the longest
+// window: base-pair windows (dxyWindow) vary in their number of sites, and a strategy chosen for the longest would run the
+// fallback of most.
+void derive_hints(const pgt_win *win, uint64_t n_win, uint64_t *max_window, uint64_t *typical_window, uint64_t *window_step) {
+    uint64_t m = 1;
+    for (uint64_t i = 0; i < n_win; ++i)
+        if (win[i].hi >= win[i].lo && win[i].hi - win[i].lo > m) m = win[i].hi - win[i].lo;
+    std::vector<uint64_t> d, len;
+    const uint64_t from = n_win > 4097 ? n_win / 2 - 2048 : 0, to = n_win > 4097 ? from + 4096 : (n_win ? n_win - 1 : 0);
+    for (uint64_t i = from; i < to; ++i) {
+        if (win[i + 1].lo >= win[i].lo) d.push_back(win[i + 1].lo - win[i].lo);
+        if (win[i].hi >= win[i].lo) len.push_back(win[i].hi - win[i].lo);
+    }
+    uint64_t typical = 0, step = 0;
+    if (!len.empty()) {
+        std::nth_element(len.begin(), len.begin() + len.size() / 2, len.end());
+        typical = len[len.size() / 2];
+    }
+    if (!d.empty()) {
+        std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
+        step = d[d.size() / 2];
+    }
+    *max_window = m;
+    *typical_window = typical;
+    *window_step = step;
+}
+
 struct HintScope {
     pgt_ctx *ctx;
     pgt::Hints saved;
     HintScope(pgt_ctx *c, const pgt_win *win, uint64_t n_win) : ctx(c), saved(c->hints) {
-        uint64_t m = 1;
-        for (uint64_t i = 0; i < n_win; ++i)
-            if (win[i].hi >= win[i].lo && win[i].hi - win[i].lo > m) m = win[i].hi - win[i].lo;
-        if (saved.max_window == 0) c->hints.max_window = m;  // an explicit hint (the caller knows the whole table) stays
-        // typical step = median distance between consecutive window starts (a sample from the middle of the
-        // table: chromosome boundaries and the Q1 carry make a few distances irregular)
-        std::vector<uint64_t> d, len;
-        const uint64_t from = n_win > 4097 ? n_win / 2 - 2048 : 0, to = n_win > 4097 ? from + 4096 : (n_win ? n_win - 1 : 0);
-        for (uint64_t i = from; i < to; ++i) {
-            if (win[i + 1].lo >= win[i].lo) d.push_back(win[i + 1].lo - win[i].lo);
-            if (win[i].hi >= win[i].lo) len.push_back(win[i].hi - win[i].lo);
-        }
-        // the typical (median) window length decides whether the group query fits, not the longest window: base-pair
-        // windows (dxyWindow) vary in their number of sites, and a strategy chosen for the longest would run the fallback
-        // of most (an explicit pgt_set_max_window stands for both)
-        if (saved.max_window == 0 && !len.empty()) {
-            std::nth_element(len.begin(), len.begin() + len.size() / 2, len.end());
-            c->hints.typical_window = len[len.size() / 2];
-        }
-        uint64_t step = 0;
-        if (!d.empty()) {
-            std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
-            step = d[d.size() / 2];
+        uint64_t m = 1, typical = 0, step = 0;
+        derive_hints(win, n_win, &m, &typical, &step);
+        if (saved.max_window == 0) {  // an explicit hint (the caller knows the whole table) stays, and stands for the typical length too
+            c->hints.max_window = m;
+            if (typical) c->hints.typical_window = typical;
         }
         if (saved.window_step == 0) c->hints.window_step = step;
     }
@@ -225,6 +236,20 @@ int pgt_set_max_window(pgt_ctx *ctx, uint64_t max_window_sites) {
     if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
     ctx->hints.max_window = max_window_sites;
     ctx->hints.typical_window = 0;  // the explicit value stands for the typical length too
+    return PGT_OK;
+}
+
+int pgt_set_typical_window(pgt_ctx *ctx, uint64_t typical_sites) {
+    if (!ctx) return ctx_fail(nullptr, PGT_EARG, "NULL context");
+    ctx->hints.typical_window = typical_sites;
+    return PGT_OK;
+}
+
+int pgt_table_hints(const pgt_win *win, uint64_t n_win, uint64_t *max_window, uint64_t *typical_window, uint64_t *window_step) {
+    if ((n_win && !win) || !max_window || !typical_window || !window_step)
+        return ctx_fail(nullptr, PGT_EARG, "pgt_table_hints: NULL argument");
+    derive_hints(win, n_win, max_window, typical_window, window_step);
+    if (*window_step == 0) *window_step = UINT64_MAX;  // "one wave per window", said explicitly: 0 would let a slice estimate its own
     return PGT_OK;
 }
 

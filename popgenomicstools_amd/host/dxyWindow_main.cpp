@@ -41,6 +41,7 @@ static void help(unsigned W, unsigned S, int minind, int fixedsite, int skip_mis
 struct Maf {
     Runs runs;
     DeviceTable dev;  // set when the file was parsed on the GPU: pos / freq / nind are then tokens 1 / 5 / 6 there
+    pgt_ctx *ctx = nullptr;  // ... the context of that GPU
     bool on_device = false;
     Column<uint32_t> pos;
     Column<double> freq;
@@ -76,19 +77,22 @@ static const uint8_t kMafSpec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_SKIP, PGT_T
 
 // the device path of read_maf (plain or gzipped text of at least 8 MiB, no column cache): only the position
 // column comes back to the host (site synchronisation and the bp-window table work on it)
-static bool read_maf_on_device(pgt_ctx *ctx, const Text &text, const char *path, Maf &m) {
+static bool read_maf_on_device(pgt_ctx *ctx, const Text &text, const char *path, Maf &m, std::string *error = nullptr) {
     Cursor hdr{text.begin(), text.end()};
     hdr.next_line();  // header (dxyWindow.cpp:284)
-    if (!ingest_on_device(ctx, hdr.p, text.end(), kMafSpec, 7, kMafWhat, path, 2, m.dev, m.runs)) return false;
+    if (!ingest_on_device(ctx, hdr.p, text.end(), kMafSpec, 7, kMafWhat, path, 2, m.dev, m.runs, error)) return false;
+    if (error && !error->empty()) return true;
     m.n = m.dev.n;
+    m.ctx = ctx;
     m.on_device = true;
     m.pos.alloc(m.n);
     check(pgt_ingest_download(ctx, m.dev.ing, 1, m.pos.data(), m.n * sizeof(uint32_t)), ctx);
     return true;
 }
 // the remaining columns of a file parsed on the GPU, for the host-side merge of differing site sets
-static void fetch_columns(pgt_ctx *ctx, Maf &m) {
+static void fetch_columns(Maf &m) {
     if (!m.on_device) return;
+    pgt_ctx *ctx = m.ctx;
     m.freq.alloc(m.n);
     m.nind.alloc(m.n);
     check(pgt_ingest_download(ctx, m.dev.ing, 5, m.freq.data(), m.n * sizeof(double)), ctx);
@@ -121,6 +125,95 @@ static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &c
         cols[0].data = m.pos.data(); cols[1].data = m.freq.data(); cols[2].data = m.nind.data();
         cache.store(m.n, m.runs, cols);
     }
+}
+
+// ---- several GPUs (PGT_DEVICES=0,1,...) ------------------------------------------------------------------------
+// The window table is cut into one contiguous block per GPU (pgt_plan_shards) as for fstWindow; the genome-wide line
+// (dxyWindow.cpp:382-385,429-433) has to see every site once, also sites no window covers, so the site axis is cut at the
+// block starts into one OWNED range per GPU, and a GPU adds its owned range to its windows as extra windows of 65536 sites
+// (block starts are multiples of 65536 on every GPU: a block's sum is taken over the same tree nodes wherever it is
+// reduced).  The main thread adds the block rows in block order.  neff and nskip of the line are integers and exact; the sum
+// is the single-GPU total to rounding (another association of the same additions; six digits are printed).
+// Columns: on the host (every GPU uploads its slice over its own PCIe link), or where the two files were parsed — file 1 on
+// the first GPU, file 2 on the second — from where a GPU copies its slice device to device.
+struct DxyColumns {
+    const uint32_t *pos = nullptr;
+    const double *p1 = nullptr, *p2 = nullptr;
+    const int32_t *n1 = nullptr, *n2 = nullptr;
+    pgt_ctx *ctx1 = nullptr, *ctx2 = nullptr;  // set: device pointers of these contexts (pos, p1, n1 on ctx1; p2, n2 on ctx2)
+};
+constexpr uint64_t kTotalBlock = 65536;
+
+static void reduce_dxy_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, const DxyColumns &col, uint64_t n_sites,
+                                  int minind, pgt_dxy_row *rows, pgt_dxy_total *tot) {
+    const size_t N = device.count();
+    std::vector<pgt_shard> shard(N);
+    check(pgt_plan_shards(win.data(), win.size(), (uint32_t)N, shard.data()), nullptr);
+    uint64_t h_max = 0, h_typical = 0, h_step = 0;  // every GPU reduces its slice as the whole table would be
+    check(pgt_table_hints(win.data(), win.size(), &h_max, &h_typical, &h_step), nullptr);
+    std::vector<uint64_t> cut(N + 1, 0);  // owned site ranges [cut[k], cut[k+1])
+    cut[N] = n_sites;
+    for (size_t k = N - 1; k >= 1; --k) {
+        const bool has = shard[k].win_end > shard[k].win_begin;
+        if (win.empty()) cut[k] = std::min<uint64_t>(n_sites / N * k / kTotalBlock * kTotalBlock, cut[k + 1]);  // global dxy only
+        else cut[k] = has ? std::min<uint64_t>(shard[k].site_lo, cut[k + 1]) : cut[k + 1];
+        if (cut[k] % kTotalBlock != 0 && cut[k] != n_sites) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
+    }
+    for (size_t k = 0; k < N; ++k) (void)device.get(k);
+    std::vector<std::vector<pgt_dxy_row>> blocks(N);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < N; ++k)
+        th.emplace_back([&, k] {
+            const pgt_shard sh = shard[k];
+            const size_t n_own = (size_t)(sh.win_end - sh.win_begin);
+            const uint64_t b0 = cut[k] / kTotalBlock, b1 = cut[k + 1] > cut[k] ? (cut[k + 1] + kTotalBlock - 1) / kTotalBlock : b0;
+            const size_t n_blocks = (size_t)(b1 - b0);
+            if (n_own + n_blocks == 0) return;
+            const uint64_t lo = cut[k], hi = std::max<uint64_t>(n_own ? sh.site_hi : lo, cut[k + 1]), n_k = hi - lo;
+            std::vector<pgt_win> local(n_own + n_blocks);
+            std::copy(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end, local.begin());
+            for (size_t i = 0; i < n_blocks; ++i) {
+                pgt_win &w = local[n_own + i];
+                w.lo = (b0 + i) * kTotalBlock;
+                w.hi = std::min<uint64_t>(w.lo + kTotalBlock, cut[k + 1]);
+                w.label_run = 0;
+                w.flags = PGT_WIN_COORDS;  // no coordinates to look up
+                w.start = w.end = 0;
+            }
+            for (pgt_win &w : local) { w.lo -= lo; w.hi -= lo; }
+            pgt_ctx *ctx = device.get(k);
+            check(pgt_set_max_window(ctx, h_max), ctx);
+            check(pgt_set_typical_window(ctx, h_typical), ctx);
+            check(pgt_set_window_step(ctx, h_step), ctx);
+            std::vector<pgt_dxy_row> out(local.size());
+            if (!col.ctx1) {
+                check(pgt_dxy_reduce(ctx, col.pos + lo, col.p1 + lo, col.p2 + lo, col.n1 + lo, col.n2 + lo, n_k, minind, local.data(),
+                                     local.size(), out.data(), nullptr), ctx);
+            } else {
+                const struct { const void *src; pgt_ctx *from; size_t elem; } part[5] = {
+                    {col.pos, col.ctx1, 4}, {col.p1, col.ctx1, 8}, {col.p2, col.ctx2, 8}, {col.n1, col.ctx1, 4}, {col.n2, col.ctx2, 4}};
+                void *d[5] = {};
+                for (int c = 0; c < 5; ++c) {
+                    check(pgt_dev_alloc(ctx, (size_t)n_k * part[c].elem + 16, &d[c]), ctx);
+                    check(pgt_dev_copy(ctx, d[c], part[c].from, static_cast<const char *>(part[c].src) + lo * part[c].elem,
+                                       (size_t)n_k * part[c].elem), ctx);
+                }
+                check(pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(d[0]), static_cast<double *>(d[1]), static_cast<double *>(d[2]),
+                                          static_cast<int32_t *>(d[3]), static_cast<int32_t *>(d[4]), n_k, minind, local.data(), local.size(),
+                                          out.data(), out.size() * sizeof(out[0]), nullptr), ctx);
+                for (void *p : d) check(pgt_dev_free(ctx, p), ctx);
+            }
+            std::copy(out.begin(), out.begin() + (ptrdiff_t)n_own, rows + sh.win_begin);
+            blocks[k].assign(out.begin() + (ptrdiff_t)n_own, out.end());
+        });
+    for (auto &t : th) t.join();
+    *tot = pgt_dxy_total{};
+    for (size_t k = 0; k < N; ++k)  // GPUs in order = blocks in order
+        for (const pgt_dxy_row &b : blocks[k]) {
+            tot->sum += b.sum;
+            tot->neff += b.neff;
+            tot->nskip += b.nskip;
+        }
 }
 
 int main(int argc, char **argv) {
@@ -165,7 +258,8 @@ int main(int argc, char **argv) {
     }
 
     PhaseTimer timer;
-    DeviceOpener device;  // HIP start-up runs beside the parse
+    DeviceOpener device;  // HIP start-up runs beside the parse; PGT_DEVICES=0,1,..: one context and host thread per GPU
+    const bool multi = device.count() > 1;
     Maf m1, m2;
     ColumnCache c1("dxyWindow maf", argv[argc - 2]), c2("dxyWindow maf", argv[argc - 1]);  // own the mappings the columns may borrow
     bool parsed = false;
@@ -184,7 +278,18 @@ int main(int argc, char **argv) {
         if (open1 && open2 && gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
-            parsed = read_maf_on_device(c, t1, argv[argc - 2], m1) && read_maf_on_device(c, t2, argv[argc - 1], m2);
+            if (multi) {  // one file per GPU, side by side: each text crosses its own PCIe link
+                std::string e1, e2;
+                bool ok1 = false, ok2 = false;
+                pgt_ctx *c2 = device.get(1);
+                std::thread other([&] { ok1 = read_maf_on_device(c, t1, argv[argc - 2], m1, &e1); });
+                ok2 = read_maf_on_device(c2, t2, argv[argc - 1], m2, &e2);
+                other.join();
+                if (ok1 && !e1.empty()) die(e1);  // Pop1's problems first, as the reference meets them
+                if (ok1 && ok2 && !e2.empty()) die(e2);
+                parsed = ok1 && ok2;
+            } else
+                parsed = read_maf_on_device(c, t1, argv[argc - 2], m1) && read_maf_on_device(c, t2, argv[argc - 1], m2);
             if (!parsed) { m1.reset(); m2.reset(); }
             timer.lap(parsed ? "gpu parse" : "gpu parse (refused)");
         }
@@ -215,13 +320,13 @@ int main(int argc, char **argv) {
                             std::memcmp(m1.pos.data(), m2.pos.data(), m1.n * sizeof(uint32_t)) == 0;
     const bool on_device = same_sites && m1.on_device && m2.on_device;  // frequencies and counts stay on the GPU
     if (same_sites) {
-        if (!on_device) { fetch_columns(device.get(), m1); fetch_columns(device.get(), m2); }
+        if (!on_device) { fetch_columns(m1); fetch_columns(m2); }
         runs = m1.runs;
         pos = m1.pos.data(); p1 = m1.freq.data(); p2 = m2.freq.data(); n1 = m1.nind.data(); n2 = m2.nind.data();
         n_sites = m1.n;
     } else {
-        fetch_columns(device.get(), m1);
-        fetch_columns(device.get(), m2);
+        fetch_columns(m1);
+        fetch_columns(m2);
         size_t r1 = 0, r2 = 0, o1 = 0, o2 = 0;
         while (r1 < m1.runs.name.size() && r2 < m2.runs.name.size()) {
             const std::string &chr1 = m1.runs.name[r1], &chr2 = m2.runs.name[r2];
@@ -257,7 +362,7 @@ int main(int argc, char **argv) {
     if (W > 0) {
         size_t n_win = 0;
         if (fixedsite) {
-            sw.build(runs, W, S, [&] { return device.get(); }, &timer);
+            sw.build(runs, W, S, [&] { return device.get(); }, &timer, multi);  // several GPUs shard a host table
         } else {
             std::vector<uint32_t> chr_len(runs.name.size());
             for (size_t r = 0; r < runs.name.size(); ++r) {
@@ -281,7 +386,10 @@ int main(int argc, char **argv) {
         pos = m1.dev.col<uint32_t>(1); p1 = m1.dev.col<double>(5); p2 = m2.dev.col<double>(5);
         n1 = m1.dev.col<int32_t>(6); n2 = m2.dev.col<int32_t>(6);
     }
-    if (sw.tab)
+    if (multi) {
+        DxyColumns col{pos, p1, p2, n1, n2, on_device ? m1.ctx : nullptr, on_device ? m2.ctx : nullptr};
+        reduce_dxy_on_devices(device, win, col, n_sites, minind, rows.data(), &tot);
+    } else if (sw.tab)
         check(pgt_dxy_reduce_tab(ctx, pos, p1, p2, n1, n2, n_sites, minind, on_device, sw.tab, rows.data(), rows.size() * sizeof(rows[0]), &tot), ctx);
     else if (on_device)
         check(pgt_dxy_reduce_cols(ctx, pos, p1, p2, n1, n2, n_sites, minind, win.data(), win.size(), rows.data(), rows.size() * sizeof(rows[0]), &tot), ctx);

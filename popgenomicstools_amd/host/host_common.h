@@ -750,13 +750,20 @@ struct DeviceTable {
 };
 // true: `tab` and `runs` hold the parsed table (errors in the text die here with the host parser's message);
 // false: the input has too many irregular lines for the device path — parse it on the host
+// error: receives the message about a bad line instead of the exit (two files parsed side by side: the caller reports
+// the first file's problem first, whichever thread met its problem first)
 inline bool ingest_on_device(pgt_ctx *ctx, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what,
-                             const char *path, size_t first_line_no, DeviceTable &tab, Runs &runs) {
+                             const char *path, size_t first_line_no, DeviceTable &tab, Runs &runs, std::string *error = nullptr) {
     const int rc = pgt_ingest_text(ctx, b, (size_t)(e - b), spec, n_tokens, &tab.ing);
     if (rc == PGT_EDOMAIN) return false;
     check(rc, ctx);
     const int64_t bad = pgt_ingest_bad_line(tab.ing);
-    if (bad >= 0) die(std::string(what) + " on line " + std::to_string(first_line_no + (size_t)bad) + " of " + path);
+    if (bad >= 0) {
+        const std::string msg = std::string(what) + " on line " + std::to_string(first_line_no + (size_t)bad) + " of " + path;
+        if (!error) die(msg);
+        *error = msg;
+        return true;
+    }
     tab.n = (size_t)pgt_ingest_rows(tab.ing);
     const uint64_t *len = nullptr, *off = nullptr;
     const uint32_t *nlen = nullptr;

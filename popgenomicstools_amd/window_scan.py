@@ -90,6 +90,17 @@ def plan_shards(win: np.ndarray, n_ranks: int) -> np.ndarray:
     return out
 
 
+def table_hints(win: np.ndarray):
+    """(longest window, typical window, typical step) of a whole host table, as the host-buffer entry points derive them
+    while the hints are unset (pgt_table_hints); the step is 2^64-1 where the table has no typical positive step."""
+    import ctypes as C
+    lib = _lib.load()
+    w = np.ascontiguousarray(win, dtype=WIN_DTYPE)
+    m, t, s = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    check(lib.pgt_table_hints(w.ctypes.data if w.size else None, w.size, C.byref(m), C.byref(t), C.byref(s)))
+    return m.value, t.value, s.value
+
+
 # ---------------------------------------------------------------------------------------------
 # raw device memory handed out by the library (pgt_rowbuf_*): quacks like the uint8 tensors the
 # *_dev wrappers take (data_ptr / numel), so it can be passed as `out=`

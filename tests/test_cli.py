@@ -543,6 +543,78 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_dxy_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
+    """dxyWindow with PGT_DEVICES=0,0 and 0,0,0 (several contexts on this box's one GPU): the window table is cut by
+    pgt_plan_shards, the genome-wide line is summed from 65536-site blocks of the owned site ranges; with the device
+    parser file 1 is parsed by the first context and file 2 by the second, and a context copies its slice of the columns
+    device to device.  stdout, stderr and the exit code are those of the single-device run: known answers, random option
+    mixes (fixed-site, bp, global, per-site, -skip_missing), nested site sets, a bad line in either file, and 3 * 10^6-site
+    files in every mode."""
+    import synth
+
+    def runs(cmd, **env):
+        one = run(cmd, env=dict(os.environ, **env))
+        for devs in ("0,0", "0,0,0"):
+            many = run(cmd, env=dict(os.environ, PGT_DEVICES=devs, **env))
+            assert (many.returncode, many.stdout, many.stderr) == (one.returncode, one.stdout, one.stderr), (cmd, devs, env, many.stderr[-300:])
+        return one
+
+    k = helpers.load_golden("dxy_kat.json")
+    m1, m2, sz = tmp_path / "p1.mafs.gz", tmp_path / "p2.mafs", tmp_path / "sizes.txt"
+    _write_maf(m1, k["header"], k["pop1"], True)
+    _write_maf(m2, k["header"], k["pop2"])
+    sz.write_text("".join(f"{c}\t{n}\n" for c, n in k["sizes"]))
+    for c in k["cases"]:
+        cmd = [hosts["dxyWindow"], "-winsize", str(c["winsize"]), "-stepsize", str(c["stepsize"]),
+               "-minind", str(k["minind"]), "-fixedsite", str(c["fixedsite"]), "-skip_missing", str(c["skip_missing"])]
+        if not c["fixedsite"]:
+            cmd += ["-sizefile", str(sz)]
+        for ingest in ("0", "1"):
+            r = runs(cmd + [str(m1), str(m2)], PGT_GPU_INGEST=ingest)
+            assert r.returncode == 0 and r.stdout == c["stdout"] and r.stderr == c["stderr"]
+    sub = [row for i, row in enumerate(k["pop2"]) if i != 1]  # pop2 lacks one site of pop1: host merge
+    _write_maf(m2, k["header"], sub)
+    for ingest in ("0", "1"):
+        r = runs([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-minind", "2", "-fixedsite", "1", str(m1), str(m2)], PGT_GPU_INGEST=ingest)
+        assert r.returncode == 0 and r.stdout
+    # a bad line: in Pop2 only, then in both (Pop1's message wins, as in the single-device run)
+    _write_maf(m2, k["header"], [k["pop2"][0], ["cA", 3, 1.5, 4]])
+    r = runs([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-fixedsite", "1", str(m1), str(m2)], PGT_GPU_INGEST="1")
+    assert r.returncode == 255 and "line 3" in r.stderr and "p2.mafs" in r.stderr
+    bad1 = tmp_path / "bad1.mafs"
+    _write_maf(bad1, k["header"], [k["pop1"][0], k["pop1"][1], ["cA", 9, -0.5, 4]])
+    r = runs([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-fixedsite", "1", str(bad1), str(m2)], PGT_GPU_INGEST="1")
+    assert r.returncode == 255 and "line 4" in r.stderr and "bad1.mafs" in r.stderr
+    # 3 * 10^6 sites in 6 uneven chromosomes
+    rng = np.random.default_rng(99)
+    n = 3_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 6, equal=False)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    f1, f2 = tmp_path / "big1.mafs", tmp_path / "big2.mafs"
+    oracle.write_maf_text(str(f1), chr_ids, pos, p1, n1)
+    oracle.write_maf_text(str(f2), chr_ids, pos, p2, n2)
+    ends = np.cumsum(np.diff(np.concatenate(([0], np.flatnonzero(np.diff(chr_ids)) + 1, [n])))) - 1
+    sz.write_text("".join(f"chr{c + 1}\t{int(pos[e]) + 777}\n" for c, e in enumerate(ends)))
+    modes = [["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-fixedsite", "1"],
+             ["-winsize", "20000", "-stepsize", "100", "-minind", "5", "-fixedsite", "1", "-skip_missing", "1"],
+             ["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-sizefile", str(sz)],
+             ["-winsize", "1000000", "-stepsize", "2000", "-minind", "3", "-sizefile", str(sz)],
+             ["-winsize", "0", "-fixedsite", "1", "-minind", "5"],
+             ["-winsize", "1", "-stepsize", "1", "-minind", "5", "-fixedsite", "1"]]
+    for opts in modes:
+        for ingest in ("1", "0"):
+            r = runs([hosts["dxyWindow"]] + opts + [str(f1), str(f2)], PGT_GPU_INGEST=ingest)
+            assert r.returncode == 0 and (r.stdout if opts[1] != "0" else r.stdout.count("\n") == 1), (opts, r.stderr[-300:])
+    # pop2 lists a subset of pop1's sites (host merge of large tables)
+    keep = np.sort(rng.choice(n, size=n - 200_000, replace=False))
+    oracle.write_maf_text(str(f2), chr_ids[keep], pos[keep], p2[keep], n2[keep])
+    for ingest in ("1", "0"):
+        r = runs([hosts["dxyWindow"]] + modes[0] + [str(f1), str(f2)], PGT_GPU_INGEST=ingest)
+        assert r.returncode == 0 and r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     """PGT_MAX_RESIDENT_SITES=<n>: the table is reduced block by block (first scan of the text on the host for runs and
     row marks, then per block: text of its rows -> GPU parser -> reduce -> print), as for an input larger than the GPU's

@@ -38,6 +38,26 @@ def test_plan_shards_alignment_follows_window_length(pgt):
         assert s["site_lo"] % (1 << 19) == 0
 
 
+def test_table_hints_of_site_and_ragged_tables(pgt):
+    """pgt_table_hints: (W, W, S) for a site-window table whatever its chromosome layout; medians for a ragged table;
+    an explicit 'no step' (2^64-1, not 0 = unknown) where windows share their starts."""
+    from popgenomicstools_amd.window_scan import table_hints
+    rng = np.random.default_rng(8)
+    for W, S in [(50_000, 10_000), (1000, 100), (300, 1)]:
+        lens = rng.integers(2 * W, 40 * W, size=9).astype(np.uint64)
+        win = pgt.build_windows_sites(lens, W, S)
+        assert table_hints(win) == (W, W, S)
+    win = np.zeros(5, dtype=win.dtype)
+    win["lo"] = [0, 10, 30, 60, 100]
+    win["hi"] = [40, 90, 35, 200, 100]
+    assert table_hints(win) == (140, 80, 30)  # longest; upper medians of the lengths of windows 0..3 (5, 40, 80, 140) and of their start distances (10, 20, 30, 40)
+    win["lo"] = 7
+    win["hi"] = 7
+    win["flags"] = 1
+    assert table_hints(win) == (1, 0, 2**64 - 1)
+    assert table_hints(win[:0]) == (1, 0, 2**64 - 1)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world,port", [(2, 29531), (3, 29532)])
 def test_gloo_ranks_match_single(tmp_path, world, port):
