@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
         if (!text.open(argv[1])) die(std::string("Unable to open Fst variance components file ") + argv[1]);
         const char *what = "fstWindow: cannot parse 'chr pos a b'";
         static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64};
-        if (const uint64_t resident = resident_limit(text.size(), 4 + 8 + 8, [&] { return device.get(); })) {
+        if (const uint64_t resident = resident_limit(text.begin(), text.end(), 4 + 8 + 8, [&] { return device.get(); })) {
             // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
             const size_t row_bytes_max = 80;
             reduce_in_passes<pgt_fst_row>(

@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
         if (!text.open(argv[1])) die(std::string("Unable to open genotypes file ") + argv[1]);
         const char *what = "hetWindow: cannot parse 'chr pos genotype'";
         static const uint8_t spec[] = {PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8};
-        if (const uint64_t resident = resident_limit(text.size(), 4 + 1, [&] { return device.get(); })) {
+        if (const uint64_t resident = resident_limit(text.begin(), text.end(), 4 + 1, [&] { return device.get(); })) {
             // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
             reduce_in_passes<pgt_het_row>(
                 device.get(), text.begin(), text.end(), W, S, resident, runs, timer,

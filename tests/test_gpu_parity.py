@@ -761,6 +761,24 @@ def test_device_api_argument_checks(pgt, ctx):
     tab.free()
 
 
+def test_device_memory_query(ctx):
+    """pgt_dev_memory (the hosts decide with it whether a table is reduced in passes): free <= total, total is this GPU's
+    HBM, and an allocation of 1 GiB through pgt_dev_alloc shows up in `free`."""
+    import ctypes as C
+    import torch
+    lib = _lib.load()
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert lib.pgt_dev_memory(ctx._ctx, C.byref(free), C.byref(total)) == _lib.PGT_OK
+    assert 0 < free.value <= total.value and total.value == torch.cuda.mem_get_info()[1] and total.value > 100e9
+    p = C.c_void_p()
+    assert lib.pgt_dev_alloc(ctx._ctx, 1 << 30, C.byref(p)) == _lib.PGT_OK
+    after = C.c_size_t(0)
+    assert lib.pgt_dev_memory(ctx._ctx, C.byref(after), None) == _lib.PGT_OK
+    assert free.value - after.value >= (1 << 30) - (64 << 20)
+    assert lib.pgt_dev_free(ctx._ctx, p) == _lib.PGT_OK
+    assert lib.pgt_dev_memory(None, C.byref(free), C.byref(total)) == _lib.PGT_EARG
+
+
 def test_fst_beyond_2_32_sites(pgt, ctx):
     """Maximum sizes: 4.4e9 sites (88 GB of columns) — site indices above 2^32 in the table, the tree
     and the kernels' address arithmetic.  Windows at the far end against float64 sums by torch."""
