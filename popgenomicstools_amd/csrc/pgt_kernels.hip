@@ -554,44 +554,6 @@ __global__ __launch_bounds__(256) void tree_up_kernel(TreeView tv, int child_lev
     }
 }
 
-// Two levels per launch (a launch costs ~7 us on the stream, a quarter of a 10^8-site dxy build's fixed cost): one
-// workgroup of 16 waves per GRANDPARENT — its up to 64 parents first (four per wave, their loads issued together), kept
-// in LDS, then the grandparent by wave 0.  Every node is the same wave-wide sum of the same 64 children as above.
-template <class Node>
-__global__ __launch_bounds__(1024) void tree_up2_kernel(TreeView tv, int child_level /*0-based slot*/, uint64_t n_child,
-                                                        uint64_t n_parent, uint64_t n_grand) {
-    __shared__ Node mid[kRadix];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    char *tree = tv.base + (size_t)blockIdx.y * tv.pair_stride;
-    const Node *__restrict__ child = reinterpret_cast<const Node *>(tree + tv.off[child_level]);
-    Node *__restrict__ parent = reinterpret_cast<Node *>(tree + tv.off[child_level + 1]);
-    Node *__restrict__ grand = reinterpret_cast<Node *>(tree + tv.off[child_level + 2]);
-    for (uint64_t g = blockIdx.x; g < n_grand; g += gridDim.x) {
-        Node v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t p = g * kRadix + (uint64_t)(wave + 16 * j), i = p * kRadix + lane;
-            v[j] = node_identity<Node>();
-            if (p < n_parent && i < n_child) v[j] = child[i];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t p = g * kRadix + (uint64_t)(wave + 16 * j);
-            const Node s = node_wave_sum(v[j]);
-            if (lane == 0) {
-                mid[wave + 16 * j] = p < n_parent ? s : node_identity<Node>();
-                if (p < n_parent) parent[p] = s;
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const Node s = node_wave_sum(mid[lane]);
-            if (lane == 0) grand[g] = s;
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // QUERY: one wave per window.
 // ------------------------------------------------------------------------------------------
@@ -1527,14 +1489,6 @@ int launch_upper(const TreeLayout &tl, const TreeView &tv, unsigned n_pairs, hip
                  int first = 2, uint64_t n_level1 = 0) {
     for (int k = first; k < tv.n_levels; ++k) {
         const uint64_t n_child = k == 1 ? n_level1 : tl.count[k - 1], n_parent = tl.count[k];
-        if (k + 1 < tv.n_levels) {  // this level and the next in one launch
-            const uint64_t n_grand = tl.count[k + 1];
-            dim3 grid2((unsigned)std::min<uint64_t>(n_grand, 1u << 16), n_pairs);
-            hipLaunchKernelGGL(tree_up2_kernel<Node>, grid2, dim3(1024), 0, s, tv, k - 1, n_child, n_parent, n_grand);
-            if (int rc = hip_fail(hipGetLastError(), "tree_up2_kernel", err)) return rc;
-            ++k;
-            continue;
-        }
         dim3 grid(query_grid(n_parent), n_pairs);
         hipLaunchKernelGGL(tree_up_kernel<Node>, grid, dim3(256), 0, s, tv, k - 1, n_child, n_parent);
         if (int rc = hip_fail(hipGetLastError(), "tree_up_kernel", err)) return rc;

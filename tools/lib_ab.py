@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of two BUILDS of libpgtwin.so in one process (markdown on stdout).
+
+Box-to-box and process-to-process differences on this pool are +-3-5 % (placement), more than most changes to a
+kernel are worth, so two builds are only comparable when their launches alternate in one process on one box.  Both
+libraries are loaded side by side (ctypes handles are per path), each gets its own context on GPU 0, and every
+configuration is measured A B B A ... on the same columns, tables and workspace.
+
+  python tools/lib_ab.py tools/_ab/libpgtwin_before.so [sites=1e8] [rounds=10]
+
+A = the library named on the command line (e.g. the previous commit's, built in a scratch worktree:
+`git worktree add gpurun_out/wt HEAD~1`, build there, copy the .so to tools/_ab/ — *.so files are not committed but
+travel with gpurun), B = the tree's own.  Reported: median build-phase and whole-step times of each and the median of
+the paired differences."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import popgenomicstools_amd as pgt  # noqa: E402
+from popgenomicstools_amd import _lib  # noqa: E402
+from popgenomicstools_amd._lib import PGT_STAT_FST  # noqa: E402
+from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
+from synth_genome import SynthGenome  # noqa: E402
+
+
+def one(ctx, fn):
+    """-> (build phase ms by the library's events, whole step ms by events on the launch stream)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn(ctx)
+    e1.record()
+    torch.cuda.synchronize()
+    return ctx.last_kernel_ms()[0], e0.elapsed_time(e1)
+
+
+def main():
+    old = os.path.abspath(sys.argv[1])
+    n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    dev = torch.device("cuda", 0)
+    ctx_b = pgt.Context(0)  # the tree's library
+    _lib._lib, _lib.LIB_PATH = None, old
+    ctx_a = pgt.Context(0)
+    assert ctx_a._lib is not ctx_b._lib
+    for c in (ctx_a, ctx_b):
+        c.set_profiling(True)
+        c.set_max_window(50_000)
+    chroms, W, S = (40 if n > 200_000_000 else 20), 50_000, 10_000
+    genome = SynthGenome(12345, n, chroms)
+    pos, a, b = genome.fst_columns_t(0, n, dev)
+    win = windows_to_device(pgt.build_windows_sites(genome.run_len, W, S), dev)
+    tree = torch.empty(2 * ctx_b.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
+    out = torch.empty(4 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
+    p1, p2, n1, n2 = genome.dxy_columns_t(0, n, dev)
+    g1, g2 = genome.genotype_t(0, 0, n, dev), genome.genotype_t(1, 0, n, dev)
+    configs = [
+        ("fstWindow", 16, lambda c: c.fst_reduce_dev(pos, a, b, win, out=out, tree=tree)),
+        ("dxyWindow (with the genome-wide line)", 24, lambda c: c.dxy_reduce_dev(pos, p1, p2, n1, n2, 5, win, out=out, tree=tree)),
+        ("hetWindow", 1, lambda c: c.het_reduce_dev(pos, g1, win, out=out, tree=tree)),
+        ("dxy + het x2 fused", 26, lambda c: c.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)),
+    ]
+    print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A\n")
+    print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms |")
+    print("|---|---|---|---|---|---|---|---|")
+    for name, bps, fn in configs:
+        for c in (ctx_a, ctx_b, ctx_a, ctx_b):
+            one(c, fn)
+        ra, rb, diff = [], [], []
+        for _ in range(rounds):
+            a1, b1, b2, a2 = one(ctx_a, fn), one(ctx_b, fn), one(ctx_b, fn), one(ctx_a, fn)
+            ra += [a1, a2]
+            rb += [b1, b2]
+            diff += [b1[0] - a1[0], b2[0] - a2[0]]
+        ma, mb = np.median([x[0] for x in ra]), np.median([x[0] for x in rb])
+        print(f"| {name} | {ma:.4f} | {mb:.4f} | {np.median(diff) * 1e3:+.1f} us | {bps * n / ma / 8e7:.1f} | {bps * n / mb / 8e7:.1f} | "
+              f"{np.median([x[1] for x in ra]):.4f} | {np.median([x[1] for x in rb]):.4f} |")
+
+
+if __name__ == "__main__":
+    main()
