@@ -71,13 +71,13 @@ int main(int argc, char **argv) {
                     Runs piece_runs;
                     if (ingest_on_device(c, pb, pe, spec, 4, what, argv[1], first_row + 1, piece, piece_runs)) {
                         if (piece.n != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
-                        check(pgt_fst_reduce_cols(c, piece.col<uint32_t>(1), piece.col<double>(2), piece.col<double>(3), piece.n, w, nw, out,
+                        if (nw) check(pgt_fst_reduce_cols(c, piece.col<uint32_t>(1), piece.col<double>(2), piece.col<double>(3), piece.n, w, nw, out,
                                                   nw * sizeof(*out)), c);
                     } else {
                         decltype(tab) t;
                         const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
                         if (k != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
-                        check(pgt_fst_reduce(c, t.pos.data(), t.a.data(), t.b.data(), k, w, nw, out), c);
+                        if (nw) check(pgt_fst_reduce(c, t.pos.data(), t.a.data(), t.b.data(), k, w, nw, out), c);
                     }
                 },
                 [&](const pgt_fst_row *r, size_t nw, const pgt_win *w) {

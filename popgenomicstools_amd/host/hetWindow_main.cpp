@@ -74,12 +74,12 @@ int main(int argc, char **argv) {
                     Runs piece_runs;
                     if (ingest_on_device(c, pb, pe, spec, 3, what, argv[1], first_row + 1, piece, piece_runs)) {
                         if (piece.n != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
-                        check(pgt_het_reduce_cols(c, piece.col<uint32_t>(1), piece.col<int8_t>(2), piece.n, w, nw, out, nw * sizeof(*out)), c);
+                        if (nw) check(pgt_het_reduce_cols(c, piece.col<uint32_t>(1), piece.col<int8_t>(2), piece.n, w, nw, out, nw * sizeof(*out)), c);
                     } else {
                         decltype(tab) t;
                         const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
                         if (k != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
-                        check(pgt_het_reduce(c, t.pos.data(), t.g.data(), k, w, nw, out), c);
+                        if (nw) check(pgt_het_reduce(c, t.pos.data(), t.g.data(), k, w, nw, out), c);
                     }
                 },
                 [&](const pgt_het_row *r, size_t nw, const pgt_win *w) {

@@ -1058,7 +1058,7 @@ inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_si
 }
 
 // The passes.  parse_and_reduce(ctx, piece_begin, piece_end, first_row /*global*/, rows_in_piece, win /*rebased*/, n_win, out)
-// parses the piece (device parser; host parser where the device refuses) and reduces the block's windows;
+// parses the piece (device parser; host parser where the device refuses) and reduces the block's windows (n_win = 0: parse only);
 // print(rows, n_win, win /*the block's entries of the global table: label_run*/) writes them.  Host memory: the mapped
 // text and the window table (24 bytes per window).
 template <class Row, class ParseReduce, class Print>
@@ -1070,22 +1070,45 @@ void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, ui
     timer.lap("scan runs");
     size_t n_win = 0;
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
-    if (n_win == 0) return;
+    const uint64_t per_pass = std::max<uint64_t>(max_resident, 2 * (uint64_t)W + 2 * kMarkEvery);
+    // rows [from, to) parsed only, from a multiple of 65536: rows no window covers still have to be well-formed (the resident
+    // paths parse the whole text before they look at the windows)
+    auto parse_only = [&](uint64_t from, uint64_t to) {
+        const uint64_t step = per_pass / kMarkEvery * kMarkEvery;
+        for (uint64_t row0 = from; row0 < to; row0 += step) {
+            const uint64_t row1 = std::min<uint64_t>(row0 + step, to), m1 = std::min<uint64_t>((row1 + kMarkEvery - 1) / kMarkEvery, (n + kMarkEvery - 1) / kMarkEvery);
+            parse_and_reduce(ctx, mark[row0 / kMarkEvery], mark[m1], row0, std::min<uint64_t>(m1 * kMarkEvery, n) - row0, nullptr, 0, nullptr);
+        }
+    };
+    if (n_win == 0) {
+        parse_only(0, n);
+        timer.lap("passes");
+        return;
+    }
     std::vector<pgt_win> win(n_win);
     check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
-    const uint64_t per_pass = std::max<uint64_t>(max_resident, 2 * (uint64_t)W + 2 * kMarkEvery);
     const uint32_t passes = (uint32_t)std::min<uint64_t>((n + per_pass - 1) / per_pass + 1, 1u << 20);
     std::vector<pgt_shard> shard(passes);
     check(pgt_plan_shards(win.data(), n_win, passes, shard.data()), nullptr);
     timer.lap("window table");
     set_site_hints(ctx, W, S);
     std::vector<Row> rows;
+    for (uint32_t p = 0; p < passes; ++p)
+        if (shard[p].win_end > shard[p].win_begin) {
+            parse_only(0, shard[p].site_lo);  // a first run without windows
+            break;
+        }
     for (uint32_t p = 0; p < passes; ++p) {
         const pgt_shard sh = shard[p];
         const size_t n_local = (size_t)(sh.win_end - sh.win_begin);
         if (n_local == 0) continue;
         if (sh.site_lo % kMarkEvery != 0) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
-        const uint64_t hi_mark = std::min<uint64_t>((sh.site_hi + kMarkEvery - 1) / kMarkEvery, (n + kMarkEvery - 1) / kMarkEvery);
+        // every row is parsed by some pass, also rows no window covers (dropped tails of a run): a bad line there is an error
+        // in the resident paths, so it is one here — a piece reaches to the next block's first row, the last one to the end
+        uint64_t cover_hi = n;
+        for (uint32_t q = p + 1; q < passes; ++q)
+            if (shard[q].win_end > shard[q].win_begin) { cover_hi = std::max<uint64_t>(sh.site_hi, shard[q].site_lo); break; }
+        const uint64_t hi_mark = std::min<uint64_t>((cover_hi + kMarkEvery - 1) / kMarkEvery, (n + kMarkEvery - 1) / kMarkEvery);
         const char *pb = mark[sh.site_lo / kMarkEvery], *pe = mark[hi_mark];
         const uint64_t rows_in_piece = std::min<uint64_t>(hi_mark * kMarkEvery, n) - sh.site_lo;
         std::vector<pgt_win> local(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end);

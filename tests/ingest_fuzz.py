@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential fuzzer of the device-side ingest at CLI level: random fst / het / MAF files (random
 separators, number formats, CRLF, blank-line stops, missing newline at the end, a bad line now and then) through
-the hosts with PGT_GPU_INGEST=1 and =0 — and, for fstWindow / hetWindow, once more with the text cut over two or three
-contexts (PGT_DEVICES=0,0[,0]: the multi-GPU path, both parsers): stdout, stderr and exit code must be identical.
+the hosts with PGT_GPU_INGEST=1 and =0 — once more with two or three contexts (PGT_DEVICES=0,0[,0]: the multi-GPU paths, both
+parsers), and for fstWindow / hetWindow in passes (PGT_MAX_RESIDENT_SITES): stdout, stderr and exit code must be identical.
 usage: python tests/ingest_fuzz.py [seconds] [seed]"""
 import os
 import subprocess
@@ -96,15 +96,24 @@ def main():
             cmd = [os.path.join(BIN, kind + "Window"), f, str(W), str(S)]
         res = [subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST=m), timeout=120) for m in ("1", "0")]
         a, b = res
-        if kind != "maf":  # several contexts on the one GPU: the text cut at line starts, shards gathered from the pieces
-            devs = "0,0" if rng.random() < 0.5 else "0,0,0"
-            for m in ("1", "0"):
-                c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST=m, PGT_DEVICES=devs), timeout=120)
-                if (c.returncode, c.stdout, c.stderr) != (a.returncode, a.stdout, a.stderr):
-                    print("MISMATCH (PGT_DEVICES=%s, PGT_GPU_INGEST=%s)" % (devs, m), cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:],
-                          "files kept in", d)
-                    sys.exit(1)
-            counts["multi"] = counts.get("multi", 0) + 1
+        # several contexts on the one GPU: fst / het: the text cut at line starts, shards gathered from the pieces; dxy: one
+        # file per context, the genome-wide line from 65536-site blocks
+        devs = "0,0" if rng.random() < 0.5 else "0,0,0"
+        for m in ("1", "0"):
+            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST=m, PGT_DEVICES=devs), timeout=120)
+            if (c.returncode, c.stdout, c.stderr) != (a.returncode, a.stdout, a.stderr):
+                print("MISMATCH (PGT_DEVICES=%s, PGT_GPU_INGEST=%s)" % (devs, m), cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:],
+                      "files kept in", d)
+                sys.exit(1)
+        counts["multi"] = counts.get("multi", 0) + 1
+        if kind != "maf":  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
+            limit = int(rng.choice([1, 70000, 150000]))
+            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit)), timeout=120)
+            ok = (c.returncode, c.stderr) == (a.returncode, a.stderr) and (c.stdout == a.stdout if a.returncode == 0 else True)
+            if not ok:
+                print("MISMATCH (PGT_MAX_RESIDENT_SITES=%d)" % limit, cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:], "files kept in", d)
+                sys.exit(1)
+            counts["passes"] = counts.get("passes", 0) + 1
         if (a.returncode, a.stdout, a.stderr) != (b.returncode, b.stdout, b.stderr):
             keep = os.path.join(d, "FAILED")
             print("MISMATCH", cmd, a.returncode, b.returncode, a.stderr[-200:], b.stderr[-200:], "files kept in", d)

@@ -664,6 +664,14 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
             r = passes(cmd, limit)
             assert (r.returncode, r.stderr) == (0, one.stderr), (W, S, limit, r.stderr[-300:])
             assert r.stdout == one.stdout, (W, S, limit)
+    # no window at all (every run shorter than the window), and a bad line: still an error, as in the resident run
+    short = tmp_path / "short.fst.txt"
+    short.write_text("".join(f"c{1 + i // 50}\t{i + 1}\t0.01\t0.2\n" for i in range(200)))
+    for body_fix in (lambda t: t, lambda t: t.replace("c3\t120\t0.01", "c3\t120\tzero")):
+        short.write_text(body_fix(short.read_text()))
+        one, r = run([hosts["fstWindow"], str(short), "60", "10"]), passes([hosts["fstWindow"], str(short), "60", "10"], 1)
+        assert (r.returncode, r.stdout, r.stderr) == (one.returncode, one.stdout, one.stderr)
+    assert one.returncode == 255 and "line 120 " in one.stderr
     # the data ends at a blank line in a later block; then a bad line there
     lines = big.read_text().splitlines(True)
     stop = tmp_path / "stop.fst.txt"
