@@ -65,17 +65,19 @@ int main(int argc, char **argv) {
             // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
             const size_t row_bytes_max = 80;
             reduce_in_passes<pgt_fst_row>(
-                device.get(), text.begin(), text.end(), W, S, resident, runs, timer,
-                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_fst_row *out) {
+                device, text.begin(), text.end(), W, S, resident, runs, timer,
+                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_fst_row *out, std::string *error) {
                     DeviceTable piece;
                     Runs piece_runs;
-                    if (ingest_on_device(c, pb, pe, spec, 4, what, argv[1], first_row + 1, piece, piece_runs)) {
+                    if (ingest_on_device(c, pb, pe, spec, 4, what, argv[1], first_row + 1, piece, piece_runs, error)) {
+                        if (error && !error->empty()) return;
                         if (piece.n != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
                         if (nw) check(pgt_fst_reduce_cols(c, piece.col<uint32_t>(1), piece.col<double>(2), piece.col<double>(3), piece.n, w, nw, out,
                                                   nw * sizeof(*out)), c);
                     } else {
                         decltype(tab) t;
-                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
+                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1, error);
+                        if (error && !error->empty()) return;
                         if (k != n_rows) die("fstWindow: a pass parsed another number of rows than the first scan counted");
                         if (nw) check(pgt_fst_reduce(c, t.pos.data(), t.a.data(), t.b.data(), k, w, nw, out), c);
                     }

@@ -68,16 +68,18 @@ int main(int argc, char **argv) {
         if (const uint64_t resident = resident_limit(text.begin(), text.end(), 4 + 1, [&] { return device.get(); })) {
             // larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block, rows printed as the blocks finish
             reduce_in_passes<pgt_het_row>(
-                device.get(), text.begin(), text.end(), W, S, resident, runs, timer,
-                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_het_row *out) {
+                device, text.begin(), text.end(), W, S, resident, runs, timer,
+                [&](pgt_ctx *c, const char *pb, const char *pe, uint64_t first_row, uint64_t n_rows, const pgt_win *w, size_t nw, pgt_het_row *out, std::string *error) {
                     DeviceTable piece;
                     Runs piece_runs;
-                    if (ingest_on_device(c, pb, pe, spec, 3, what, argv[1], first_row + 1, piece, piece_runs)) {
+                    if (ingest_on_device(c, pb, pe, spec, 3, what, argv[1], first_row + 1, piece, piece_runs, error)) {
+                        if (error && !error->empty()) return;
                         if (piece.n != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
                         if (nw) check(pgt_het_reduce_cols(c, piece.col<uint32_t>(1), piece.col<int8_t>(2), piece.n, w, nw, out, nw * sizeof(*out)), c);
                     } else {
                         decltype(tab) t;
-                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1);
+                        const size_t k = parse_table(pb, pe, t, piece_runs, what, argv[1], first_row + 1, error);
+                        if (error && !error->empty()) return;
                         if (k != n_rows) die("hetWindow: a pass parsed another number of rows than the first scan counted");
                         if (nw) check(pgt_het_reduce(c, t.pos.data(), t.g.data(), k, w, nw, out), c);
                     }

@@ -34,6 +34,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -981,7 +983,8 @@ void reduce_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, ui
 // that pgt_plan_shards adds; block starts are multiples of 65536 rows, so they are marked) is parsed on the GPU, the block's
 // windows are reduced and its rows are printed before the next pass starts — the output streams as the reference's does.
 // GPU memory per pass: the text and the columns of one block.  A bad line is reported when its pass reaches it (rows of
-// earlier passes are out by then — the reference would have printed them too).  First listed device only.
+// earlier passes are out by then — the reference would have printed them too).  With PGT_DEVICES the blocks go round the
+// listed GPUs (every GPU uploads over its own PCIe link) and are printed in order.
 constexpr uint64_t kMarkEvery = 65536;  // rows between two byte marks = the smallest shard alignment of pgt_plan_shards
 
 // runs of chromosome names, the number of rows and the row marks of [b,e); stops at the first blank line like the parsers
@@ -1057,13 +1060,14 @@ inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_si
     return (uint64_t)(0.6 * (double)free_b / per_site);
 }
 
-// The passes.  parse_and_reduce(ctx, piece_begin, piece_end, first_row /*global*/, rows_in_piece, win /*rebased*/, n_win, out)
-// parses the piece (device parser; host parser where the device refuses) and reduces the block's windows (n_win = 0: parse only);
+// The passes.  parse_and_reduce(ctx, piece_begin, piece_end, first_row /*global*/, rows_in_piece, win /*rebased*/, n_win, out, error)
+// (error: NULL = exit on a bad line, else the message goes there) parses the piece (device parser; host parser where the device refuses) and reduces the block's windows (n_win = 0: parse only);
 // print(rows, n_win, win /*the block's entries of the global table: label_run*/) writes them.  Host memory: the mapped
 // text and the window table (24 bytes per window).
 template <class Row, class ParseReduce, class Print>
-void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, uint32_t S, uint64_t max_resident, Runs &runs,
+void reduce_in_passes(DeviceOpener &device, const char *b, const char *e, uint32_t W, uint32_t S, uint64_t max_resident, Runs &runs,
                       PhaseTimer &timer, ParseReduce parse_and_reduce, Print print) {
+    pgt_ctx *ctx = device.get();
     std::vector<const char *> mark;
     const char *data_end = b;
     const size_t n = scan_runs_and_marks(b, e, runs, mark, &data_end);
@@ -1077,7 +1081,7 @@ void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, ui
         const uint64_t step = per_pass / kMarkEvery * kMarkEvery;
         for (uint64_t row0 = from; row0 < to; row0 += step) {
             const uint64_t row1 = std::min<uint64_t>(row0 + step, to), m1 = std::min<uint64_t>((row1 + kMarkEvery - 1) / kMarkEvery, (n + kMarkEvery - 1) / kMarkEvery);
-            parse_and_reduce(ctx, mark[row0 / kMarkEvery], mark[m1], row0, std::min<uint64_t>(m1 * kMarkEvery, n) - row0, nullptr, 0, nullptr);
+            parse_and_reduce(ctx, mark[row0 / kMarkEvery], mark[m1], row0, std::min<uint64_t>(m1 * kMarkEvery, n) - row0, nullptr, 0, nullptr, nullptr);
         }
     };
     if (n_win == 0) {
@@ -1091,17 +1095,15 @@ void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, ui
     std::vector<pgt_shard> shard(passes);
     check(pgt_plan_shards(win.data(), n_win, passes, shard.data()), nullptr);
     timer.lap("window table");
-    set_site_hints(ctx, W, S);
-    std::vector<Row> rows;
     for (uint32_t p = 0; p < passes; ++p)
         if (shard[p].win_end > shard[p].win_begin) {
             parse_only(0, shard[p].site_lo);  // a first run without windows
             break;
         }
-    for (uint32_t p = 0; p < passes; ++p) {
+    // one pass: block p on context c -> its rows
+    auto run_pass = [&](uint32_t p, pgt_ctx *c, std::vector<Row> &rows, std::string *error) {
         const pgt_shard sh = shard[p];
         const size_t n_local = (size_t)(sh.win_end - sh.win_begin);
-        if (n_local == 0) continue;
         if (sh.site_lo % kMarkEvery != 0) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
         // every row is parsed by some pass, also rows no window covers (dropped tails of a run): a bad line there is an error
         // in the resident paths, so it is one here — a piece reaches to the next block's first row, the last one to the end
@@ -1114,9 +1116,69 @@ void reduce_in_passes(pgt_ctx *ctx, const char *b, const char *e, uint32_t W, ui
         std::vector<pgt_win> local(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end);
         for (pgt_win &w : local) { w.lo -= sh.site_lo; w.hi -= sh.site_lo; }
         rows.resize(n_local);
-        parse_and_reduce(ctx, pb, pe, sh.site_lo, rows_in_piece, local.data(), n_local, rows.data());
-        print(rows.data(), n_local, win.data() + sh.win_begin);
+        parse_and_reduce(c, pb, pe, sh.site_lo, rows_in_piece, local.data(), n_local, rows.data(), error);
+    };
+    const size_t N = device.count();
+    for (size_t k = 0; k < N; ++k) set_site_hints(device.get(k), W, S);
+    if (N == 1) {
+        std::vector<Row> rows;
+        for (uint32_t p = 0; p < passes; ++p) {
+            if (shard[p].win_end == shard[p].win_begin) continue;
+            run_pass(p, ctx, rows, nullptr);
+            print(rows.data(), rows.size(), win.data() + shard[p].win_begin);
+        }
+        timer.lap("passes");
+        return;
     }
+    // PGT_DEVICES: block p goes to GPU p mod N (a pass is bound by its text upload, and every GPU has its own PCIe link);
+    // the main thread prints the blocks in order as they finish — and reports a bad line when its block's turn has come, so
+    // that the message and the rows before it are those of the one-GPU run; a GPU runs at most two rounds ahead of the printer
+    struct Done { std::vector<Row> rows; std::string error; bool ready = false; };
+    std::vector<Done> done(passes);
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t printed = 0;  // blocks below this are out
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < N; ++k)
+        th.emplace_back([&, k] {
+            for (uint32_t p = (uint32_t)k; p < passes; p += (uint32_t)N) {
+                if (shard[p].win_end == shard[p].win_begin) continue;
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv.wait(lock, [&] { return p < printed + 2 * N; });
+                }
+                std::vector<Row> rows;
+                std::string error;
+                run_pass(p, device.get(k), rows, &error);
+                const bool failed = !error.empty();
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    done[p].rows = std::move(rows);
+                    done[p].error = std::move(error);
+                    done[p].ready = true;
+                }
+                cv.notify_all();
+                if (failed) return;  // the main thread ends the run when this block's turn comes
+            }
+        });
+    for (uint32_t p = 0; p < passes; ++p) {
+        if (shard[p].win_end != shard[p].win_begin) {
+            std::vector<Row> rows;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return done[p].ready; });
+                if (!done[p].error.empty()) die(done[p].error);
+                rows = std::move(done[p].rows);
+            }
+            print(rows.data(), rows.size(), win.data() + shard[p].win_begin);
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            printed = p + 1;
+        }
+        cv.notify_all();
+    }
+    for (auto &t : th) t.join();
     timer.lap("passes");
 }
 

@@ -108,7 +108,10 @@ def main():
         counts["multi"] = counts.get("multi", 0) + 1
         if kind != "maf":  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
             limit = int(rng.choice([1, 70000, 150000]))
-            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit)), timeout=120)
+            env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))
+            if rng.random() < 0.5:
+                env["PGT_DEVICES"] = devs  # the blocks go round the contexts
+            c = subprocess.run(cmd, capture_output=True, env=env, timeout=120)
             ok = (c.returncode, c.stderr) == (a.returncode, a.stderr) and (c.stdout == a.stdout if a.returncode == 0 else True)
             if not ok:
                 print("MISMATCH (PGT_MAX_RESIDENT_SITES=%d)" % limit, cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:], "files kept in", d)

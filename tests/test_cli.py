@@ -664,6 +664,9 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
             r = passes(cmd, limit)
             assert (r.returncode, r.stderr) == (0, one.stderr), (W, S, limit, r.stderr[-300:])
             assert r.stdout == one.stdout, (W, S, limit)
+        for devs in ("0,0", "0,0,0"):  # the blocks go round several contexts and are printed in order
+            r = passes(cmd, 300_000, PGT_DEVICES=devs)
+            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, devs, r.stderr[-300:])
     # no window at all (every run shorter than the window), and a bad line: still an error, as in the resident run
     short = tmp_path / "short.fst.txt"
     short.write_text("".join(f"c{1 + i // 50}\t{i + 1}\t0.01\t0.2\n" for i in range(200)))
@@ -687,6 +690,8 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     assert r.returncode == 255 and r.stderr == one.stderr
     full = run([hosts["fstWindow"], str(big), "50000", "10000"]).stdout
     assert r.stdout and full.startswith(r.stdout) and len(r.stdout) < len(full)  # what was printed before the bad block is right
+    r = passes(cmd, 300_000, PGT_DEVICES="0,0,0")
+    assert r.returncode == 255 and r.stderr == one.stderr and full.startswith(r.stdout) and len(r.stdout) < len(full)
     os.unlink(stop)
     os.unlink(big)
     g = synth.het_column(rng, n)
@@ -701,6 +706,8 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
         for limit in (1, 500_000):
             r = passes(cmd, limit)
             assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, limit, r.stderr[-300:])
+        r = passes(cmd, 200_000, PGT_DEVICES="0,0")
+        assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, r.stderr[-300:])
 
 
 @pytest.mark.gpu
