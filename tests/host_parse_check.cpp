@@ -10,7 +10,8 @@
 //      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused;
 //   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
 //      per piece and stitched with Runs::add are the runs of the whole text;
-//   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks.
+//   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks;
+//   7. HostBuf (huge-page mappings for columns, rows and inflated text): alignment, size, every byte writable.
 #include <dirent.h>
 
 #include <cinttypes>
@@ -370,6 +371,27 @@ int main(int argc, char **argv) {
             for (size_t k = 0; k * kMarkEvery < n; ++k) CHECK(mark[k] == b + line_start[k * kMarkEvery]);
             CHECK(mark[(n + kMarkEvery - 1) / kMarkEvery] == data_end);
         }
+    }
+    {   // 7. HostBuf: malloc below 8 MiB, a 2-MiB-aligned mapping of whole huge pages from there on; every byte writable; release and re-use
+        HostBuf h;
+        for (size_t bytes : {(size_t)1, (size_t)4096, ((size_t)8 << 20) - 1, (size_t)8 << 20, ((size_t)8 << 20) + 1, ((size_t)33 << 20) + 12345}) {
+            h.alloc(bytes);
+            CHECK(h.p != nullptr);
+            const bool big = bytes >= ((size_t)8 << 20);
+            CHECK(big == (h.mapped != 0));
+            if (big) {
+                CHECK(reinterpret_cast<uintptr_t>(h.p) % ((size_t)2 << 20) == 0);
+                CHECK(h.mapped >= bytes && h.mapped % ((size_t)2 << 20) == 0 && h.mapped < bytes + ((size_t)2 << 20));
+            }
+            std::memset(h.p, 0x5a, bytes);
+            CHECK(static_cast<unsigned char *>(h.p)[bytes - 1] == 0x5a && static_cast<unsigned char *>(h.p)[0] == 0x5a);
+        }
+        h.release();
+        CHECK(h.p == nullptr && h.mapped == 0);
+        Column<double> c;
+        c.alloc((size_t)3 << 20);  // 24 MiB
+        c[((size_t)3 << 20) - 1] = 2.5;
+        CHECK(c.data()[((size_t)3 << 20) - 1] == 2.5);
     }
     std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);
     return fails ? 1 : 0;
