@@ -11,7 +11,9 @@ configuration is measured A B B A ... on the same columns, tables and workspace.
 A = the library named on the command line (e.g. the previous commit's, built in a scratch worktree:
 `git worktree add gpurun_out/wt HEAD~1`, build there, copy the .so to tools/_ab/ — *.so files are not committed but
 travel with gpurun), B = the tree's own.  Reported: median build-phase and whole-step times of each and the median of
-the paired differences."""
+the paired differences.  Every launch here starts on an idle GPU (a synchronise after each call, so that the two
+libraries never overlap): the absolute rates read 2-5 points below those of back-to-back launches (bench.py,
+measure_configs.py); only the difference between A and B is the result."""
 import os
 import sys
 
