@@ -349,15 +349,12 @@ def sharded_scan(win: np.ndarray, row_dtype: np.dtype, load_columns, reduce_rows
 
 
 def table_hints(win: np.ndarray):
-    """(longest window, typical step) of a whole window table: what pgt_set_max_window / pgt_set_window_step
-    should be given on every rank that reduces a slice of it (the median start distance, as the host-buffer
-    entry points derive it)."""
-    if win.size == 0:
-        return 0, 0
-    span = win["hi"].astype(np.int64) - win["lo"].astype(np.int64)
-    d = np.diff(win["lo"].astype(np.int64))
-    d = d[d >= 0]
-    return int(max(span.max(), 1)), (int(np.median(d)) if d.size else 0)
+    """(longest window, typical step, typical window) of a whole window table: what every rank that reduces a slice
+    of it passes to ctx.hints — the library's own derivation (pgt_table_hints: what the host-buffer entry points
+    use while the hints are unset), so a sharded scan takes the strategy and tree levels of the single call."""
+    from .window_scan import table_hints as derive
+    longest, typical, step = derive(win)
+    return longest, step, typical
 
 
 TOTAL_BLOCK = 1 << 16  # sites per block of the genome-wide dxy total (= the smallest shard alignment)

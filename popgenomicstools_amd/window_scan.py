@@ -588,6 +588,7 @@ class Context:
         """Performance hint for the *_dev calls: no window is longer than `sites` (0 = unknown)."""
         self._check(self._lib.pgt_set_max_window(self._ctx, int(sites)))
         self._hints = (int(sites), getattr(self, "_hints", (0, 0))[1])
+        self._typical = 0  # the library resets it: the explicit longest window stands for the typical one
 
     def set_window_step(self, sites: int):
         """Performance hint for the *_dev calls: consecutive windows start `sites` apart (0 = unknown);
@@ -595,20 +596,28 @@ class Context:
         self._check(self._lib.pgt_set_window_step(self._ctx, int(sites)))
         self._hints = (getattr(self, "_hints", (0, 0))[0], int(sites))
 
-    def hints(self, max_window: int, window_step: int):
-        """with ctx.hints(max_window, step): ... — both hints for the duration of the block, then the previous ones."""
+    def set_typical_window(self, sites: int):
+        """Performance hint for tables whose windows vary in length (base-pair windows): the typical length decides
+        between the query strategies instead of the longest.  After set_max_window, which resets it (0 = the same)."""
+        self._check(self._lib.pgt_set_typical_window(self._ctx, int(sites)))
+        self._typical = int(sites)
+
+    def hints(self, max_window: int, window_step: int, typical_window: int = 0):
+        """with ctx.hints(max_window, step[, typical]): ... — the hints for the duration of the block, then the previous ones."""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
-            saved = getattr(self, "_hints", (0, 0))
+            saved = getattr(self, "_hints", (0, 0)) + (getattr(self, "_typical", 0),)
             self.set_max_window(max_window)
             self.set_window_step(window_step)
+            self.set_typical_window(typical_window)
             try:
                 yield self
             finally:
                 self.set_max_window(saved[0])
                 self.set_window_step(saved[1])
+                self.set_typical_window(saved[2])
         return scope()
 
     # ---- per-kernel timing ------------------------------------------------------------------
