@@ -2,7 +2,7 @@
 """Where the device parser starts to pay: fstWindow end to end (wall time of the process) with PGT_GPU_INGEST=0 and =1,
 alternating, at several table sizes.  The host parser runs beside HIP start-up and uploads 20 B of columns per line; the
 device parser has to wait for HIP and uploads the ~33 B of text per line.  Markdown on stdout.
-usage: python tools/ingest_crossover.py [lines ...]"""
+usage: python tests/ingest_crossover.py [lines ...]"""
 import os
 import subprocess
 import sys
@@ -13,8 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_bind  # noqa: E402  (only its text writer: the table has to come from somewhere)
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this script lives in tests/: it writes its tables with the oracle's text writer
+import oracle_bind  # noqa: E402
 import synth  # noqa: E402
 
 
