@@ -60,7 +60,6 @@ struct DevBuf {
     }
 };
 
-// RAII: the host-buffer entry points know the table, so they set the max-window hint themselves
 // The three hints of a host table (pgt_table_hints): longest window; typical (median) length and typical step = median
 // distance between consecutive window starts, both over a sample from the middle of the table (chromosome boundaries and
 // the Q1 carry make a few distances irregular).  The typical length decides whether the group query fits, not the longest
@@ -90,6 +89,7 @@ void derive_hints(const pgt_win *win, uint64_t n_win, uint64_t *max_window, uint
     *window_step = step;
 }
 
+// RAII: the host-buffer entry points know the table, so they set the hints that are unset themselves
 struct HintScope {
     pgt_ctx *ctx;
     pgt::Hints saved;
