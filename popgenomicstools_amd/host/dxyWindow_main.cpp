@@ -144,52 +144,82 @@ struct DxyColumns {
 };
 constexpr uint64_t kTotalBlock = 65536;
 
+// The plan of N blocks: window blocks (pgt_plan_shards), owned site ranges [cut[k], cut[k+1]) and the hints of the whole table
+struct DxyBlockPlan {
+    std::vector<pgt_shard> shard;
+    std::vector<uint64_t> cut;
+    uint64_t h_max = 0, h_typical = 0, h_step = 0;
+};
+static DxyBlockPlan plan_dxy_blocks(const std::vector<pgt_win> &win, uint64_t n_sites, size_t N) {
+    DxyBlockPlan pl;
+    pl.shard.resize(N);
+    check(pgt_plan_shards(win.data(), win.size(), (uint32_t)N, pl.shard.data()), nullptr);
+    check(pgt_table_hints(win.data(), win.size(), &pl.h_max, &pl.h_typical, &pl.h_step), nullptr);  // every block is reduced as the whole table would be
+    pl.cut.assign(N + 1, 0);
+    pl.cut[N] = n_sites;
+    for (size_t k = N - 1; k >= 1; --k) {
+        const bool has = pl.shard[k].win_end > pl.shard[k].win_begin;
+        if (win.empty()) pl.cut[k] = std::min<uint64_t>(n_sites / N * k / kTotalBlock * kTotalBlock, pl.cut[k + 1]);  // global dxy only
+        else pl.cut[k] = has ? std::min<uint64_t>(pl.shard[k].site_lo, pl.cut[k + 1]) : pl.cut[k + 1];
+        if (pl.cut[k] % kTotalBlock != 0 && pl.cut[k] != n_sites) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
+    }
+    return pl;
+}
+
+// Block k on ctx: its windows + the 65536-site blocks of its owned range, re-based to its first site, through
+// reduce(first site, sites, windows, n, rows out).  false: the block is empty.  out = the window rows, then the block rows.
+template <class Reduce>
+static bool run_dxy_block(const DxyBlockPlan &pl, size_t k, const std::vector<pgt_win> &win, pgt_ctx *ctx, Reduce reduce,
+                          std::vector<pgt_dxy_row> &out, size_t &n_own) {
+    const pgt_shard sh = pl.shard[k];
+    n_own = (size_t)(sh.win_end - sh.win_begin);
+    const uint64_t b0 = pl.cut[k] / kTotalBlock, b1 = pl.cut[k + 1] > pl.cut[k] ? (pl.cut[k + 1] + kTotalBlock - 1) / kTotalBlock : b0;
+    const size_t n_blocks = (size_t)(b1 - b0);
+    if (n_own + n_blocks == 0) return false;
+    const uint64_t lo = pl.cut[k], hi = std::max<uint64_t>(n_own ? sh.site_hi : lo, pl.cut[k + 1]);
+    std::vector<pgt_win> local(n_own + n_blocks);
+    std::copy(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end, local.begin());
+    for (size_t i = 0; i < n_blocks; ++i) {
+        pgt_win &w = local[n_own + i];
+        w.lo = (b0 + i) * kTotalBlock;
+        w.hi = std::min<uint64_t>(w.lo + kTotalBlock, pl.cut[k + 1]);
+        w.label_run = 0;
+        w.flags = PGT_WIN_COORDS;  // no coordinates to look up
+        w.start = w.end = 0;
+    }
+    for (pgt_win &w : local) { w.lo -= lo; w.hi -= lo; }
+    check(pgt_set_max_window(ctx, pl.h_max), ctx);
+    check(pgt_set_typical_window(ctx, pl.h_typical), ctx);
+    check(pgt_set_window_step(ctx, pl.h_step), ctx);
+    out.resize(local.size());
+    reduce(lo, hi - lo, local.data(), local.size(), out.data());
+    return true;
+}
+static void add_block_rows(pgt_dxy_total &tot, const pgt_dxy_row *b, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        tot.sum += b[i].sum;
+        tot.neff += b[i].neff;
+        tot.nskip += b[i].nskip;
+    }
+}
+
 static void reduce_dxy_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, const DxyColumns &col, uint64_t n_sites,
                                   int minind, pgt_dxy_row *rows, pgt_dxy_total *tot) {
     const size_t N = device.count();
-    std::vector<pgt_shard> shard(N);
-    check(pgt_plan_shards(win.data(), win.size(), (uint32_t)N, shard.data()), nullptr);
-    uint64_t h_max = 0, h_typical = 0, h_step = 0;  // every GPU reduces its slice as the whole table would be
-    check(pgt_table_hints(win.data(), win.size(), &h_max, &h_typical, &h_step), nullptr);
-    std::vector<uint64_t> cut(N + 1, 0);  // owned site ranges [cut[k], cut[k+1])
-    cut[N] = n_sites;
-    for (size_t k = N - 1; k >= 1; --k) {
-        const bool has = shard[k].win_end > shard[k].win_begin;
-        if (win.empty()) cut[k] = std::min<uint64_t>(n_sites / N * k / kTotalBlock * kTotalBlock, cut[k + 1]);  // global dxy only
-        else cut[k] = has ? std::min<uint64_t>(shard[k].site_lo, cut[k + 1]) : cut[k + 1];
-        if (cut[k] % kTotalBlock != 0 && cut[k] != n_sites) die("pgt_plan_shards returned a block start that is not a multiple of 65536");
-    }
+    const DxyBlockPlan pl = plan_dxy_blocks(win, n_sites, N);
     for (size_t k = 0; k < N; ++k) (void)device.get(k);
     std::vector<std::vector<pgt_dxy_row>> blocks(N);
     std::vector<std::thread> th;
     for (size_t k = 0; k < N; ++k)
         th.emplace_back([&, k] {
-            const pgt_shard sh = shard[k];
-            const size_t n_own = (size_t)(sh.win_end - sh.win_begin);
-            const uint64_t b0 = cut[k] / kTotalBlock, b1 = cut[k + 1] > cut[k] ? (cut[k + 1] + kTotalBlock - 1) / kTotalBlock : b0;
-            const size_t n_blocks = (size_t)(b1 - b0);
-            if (n_own + n_blocks == 0) return;
-            const uint64_t lo = cut[k], hi = std::max<uint64_t>(n_own ? sh.site_hi : lo, cut[k + 1]), n_k = hi - lo;
-            std::vector<pgt_win> local(n_own + n_blocks);
-            std::copy(win.begin() + (ptrdiff_t)sh.win_begin, win.begin() + (ptrdiff_t)sh.win_end, local.begin());
-            for (size_t i = 0; i < n_blocks; ++i) {
-                pgt_win &w = local[n_own + i];
-                w.lo = (b0 + i) * kTotalBlock;
-                w.hi = std::min<uint64_t>(w.lo + kTotalBlock, cut[k + 1]);
-                w.label_run = 0;
-                w.flags = PGT_WIN_COORDS;  // no coordinates to look up
-                w.start = w.end = 0;
-            }
-            for (pgt_win &w : local) { w.lo -= lo; w.hi -= lo; }
             pgt_ctx *ctx = device.get(k);
-            check(pgt_set_max_window(ctx, h_max), ctx);
-            check(pgt_set_typical_window(ctx, h_typical), ctx);
-            check(pgt_set_window_step(ctx, h_step), ctx);
-            std::vector<pgt_dxy_row> out(local.size());
-            if (!col.ctx1) {
-                check(pgt_dxy_reduce(ctx, col.pos + lo, col.p1 + lo, col.p2 + lo, col.n1 + lo, col.n2 + lo, n_k, minind, local.data(),
-                                     local.size(), out.data(), nullptr), ctx);
-            } else {
+            std::vector<pgt_dxy_row> out;
+            size_t n_own = 0;
+            const bool any = run_dxy_block(pl, k, win, ctx, [&](uint64_t lo, uint64_t n_k, const pgt_win *w, size_t nw, pgt_dxy_row *o) {
+                if (!col.ctx1) {
+                    check(pgt_dxy_reduce(ctx, col.pos + lo, col.p1 + lo, col.p2 + lo, col.n1 + lo, col.n2 + lo, n_k, minind, w, nw, o, nullptr), ctx);
+                    return;
+                }
                 const struct { const void *src; pgt_ctx *from; size_t elem; } part[5] = {
                     {col.pos, col.ctx1, 4}, {col.p1, col.ctx1, 8}, {col.p2, col.ctx2, 8}, {col.n1, col.ctx1, 4}, {col.n2, col.ctx2, 4}};
                 void *d[5] = {};
@@ -199,21 +229,140 @@ static void reduce_dxy_on_devices(DeviceOpener &device, const std::vector<pgt_wi
                                        (size_t)n_k * part[c].elem), ctx);
                 }
                 check(pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(d[0]), static_cast<double *>(d[1]), static_cast<double *>(d[2]),
-                                          static_cast<int32_t *>(d[3]), static_cast<int32_t *>(d[4]), n_k, minind, local.data(), local.size(),
-                                          out.data(), out.size() * sizeof(out[0]), nullptr), ctx);
+                                          static_cast<int32_t *>(d[3]), static_cast<int32_t *>(d[4]), n_k, minind, w, nw, o, nw * sizeof(*o), nullptr), ctx);
                 for (void *p : d) check(pgt_dev_free(ctx, p), ctx);
-            }
-            std::copy(out.begin(), out.begin() + (ptrdiff_t)n_own, rows + sh.win_begin);
+            }, out, n_own);
+            if (!any) return;
+            std::copy(out.begin(), out.begin() + (ptrdiff_t)n_own, rows + pl.shard[k].win_begin);
             blocks[k].assign(out.begin() + (ptrdiff_t)n_own, out.end());
         });
     for (auto &t : th) t.join();
     *tot = pgt_dxy_total{};
-    for (size_t k = 0; k < N; ++k)  // GPUs in order = blocks in order
-        for (const pgt_dxy_row &b : blocks[k]) {
-            tot->sum += b.sum;
-            tot->neff += b.neff;
-            tot->nskip += b.nskip;
+    for (size_t k = 0; k < N; ++k) add_block_rows(*tot, blocks[k].data(), blocks[k].size());  // GPUs in order = blocks in order
+}
+
+// ---- two MAF files larger than the GPU: in passes (PGT_MAX_RESIDENT_SITES, or decided from the free memory) ----------------
+// As for fstWindow (host_common.h: reduce_in_passes), with the blocks of the several-GPU path above run one after the other
+// on the first GPU: a first scan of both texts for runs and row marks; the passes need both files to list the SAME sites (run
+// for run here; position for position checked block by block on what the device parsed — files whose site lists differ go
+// through the host merge, which holds everything: -> false, the resident path runs).  Base-pair windows need every position
+// before the first window is known: one extra pass over file 1 that keeps only its position column (4 B per site on the
+// host).  Then per block: the text of its rows of both files -> device parser -> reduce -> its rows printed; the genome-wide
+// line from the blocks' 65536-site rows, in order, as on several GPUs.
+static bool dxy_in_passes(DeviceOpener &device, const Text &t1, const Text &t2, const char *path1, const char *path2, uint32_t W, uint32_t S,
+                          int minind, int fixedsite, int skip_missing, const std::map<std::string, uint32_t> &chrsize,
+                          uint64_t max_resident, PhaseTimer &timer) {
+    struct File { const char *b, *e, *end; Runs runs; std::vector<const char *> mark; size_t n; const char *path; } f[2];
+    const Text *texts[2] = {&t1, &t2};
+    const char *paths[2] = {path1, path2};
+    for (int i = 0; i < 2; ++i) {
+        Cursor hdr{texts[i]->begin(), texts[i]->end()};
+        hdr.next_line();  // header (dxyWindow.cpp:284)
+        f[i].b = hdr.p;
+        f[i].e = texts[i]->end();
+        f[i].path = paths[i];
+        f[i].n = scan_runs_and_marks(f[i].b, f[i].e, f[i].runs, f[i].mark, &f[i].end);
+    }
+    timer.lap("scan runs");
+    if (f[0].n == 0 || f[1].n == 0) die("dxyWindow: a MAF file holds no sites");
+    if (f[0].runs.name[0] != f[1].runs.name[0]) die("Chromosomes in MAF files differ");  // dxyWindow.cpp:295-298
+    if (f[0].n != f[1].n || f[0].runs.name != f[1].runs.name || f[0].runs.len != f[1].runs.len) return false;
+    const uint64_t n = f[0].n;
+    const Runs &runs = f[0].runs;
+    pgt_ctx *ctx = device.get();
+    timer.lap("wait for HIP");
+    const uint64_t last_mark = (n + kMarkEvery - 1) / kMarkEvery;
+    // rows [row0, row1) of file i (row0 a multiple of 65536) parsed: on the GPU, or by the host parser where the device refuses
+    struct Piece { Maf m; uint64_t rows = 0; };
+    auto parse_piece = [&](int i, uint64_t row0, uint64_t row1, Piece &pc) {
+        const uint64_t m1 = std::min<uint64_t>((row1 + kMarkEvery - 1) / kMarkEvery, last_mark);
+        const char *pb = f[i].mark[row0 / kMarkEvery], *pe = f[i].mark[m1];
+        pc.rows = std::min<uint64_t>(m1 * kMarkEvery, n) - row0;
+        if (ingest_on_device(ctx, pb, pe, kMafSpec, 7, kMafWhat, f[i].path, row0 + 2, pc.m.dev, pc.m.runs)) {
+            pc.m.n = pc.m.dev.n;
+            pc.m.ctx = ctx;
+            pc.m.on_device = true;
+        } else {
+            pc.m.n = parse_table(pb, pe, pc.m, pc.m.runs, kMafWhat, f[i].path, row0 + 2);
         }
+        if (pc.m.n != pc.rows) die("dxyWindow: a pass parsed another number of rows than the first scan counted");
+    };
+    const uint64_t per_pass = std::max<uint64_t>(max_resident, 4 * kMarkEvery) / kMarkEvery * kMarkEvery;
+    std::vector<uint32_t> pos_all;  // base-pair windows only
+    std::vector<pgt_win> win;
+    if (W > 0) {
+        size_t n_win = 0;
+        if (fixedsite) {
+            check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+            win.resize(n_win);
+            if (n_win) check(pgt_build_windows_sites(runs.len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+        } else {
+            pos_all.resize(n);
+            for (uint64_t row0 = 0; row0 < n; row0 += per_pass) {
+                Piece pc;
+                parse_piece(0, row0, std::min<uint64_t>(row0 + per_pass, n), pc);
+                if (pc.m.on_device) check(pgt_ingest_download(ctx, pc.m.dev.ing, 1, pos_all.data() + row0, pc.rows * sizeof(uint32_t)), ctx);
+                else std::memcpy(pos_all.data() + row0, pc.m.pos.data(), pc.rows * sizeof(uint32_t));
+            }
+            timer.lap("positions");
+            std::vector<uint32_t> chr_len(runs.name.size());
+            for (size_t r = 0; r < runs.name.size(); ++r) {
+                auto it = chrsize.find(runs.name[r]);
+                if (it == chrsize.end()) die("Unable to determine size for " + runs.name[r]);  // dxyWindow.cpp:340-343
+                chr_len[r] = it->second;
+            }
+            check(pgt_build_windows_bp(pos_all.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, nullptr, 0, &n_win), nullptr);
+            win.resize(n_win);
+            if (n_win) check(pgt_build_windows_bp(pos_all.data(), runs.len.data(), chr_len.data(), runs.len.size(), W, S, win.data(), win.size(), &n_win), nullptr);
+        }
+    }
+    const size_t passes = (size_t)std::min<uint64_t>((n + per_pass - 1) / per_pass + (win.empty() ? 0 : 1), 1u << 20);
+    const DxyBlockPlan pl = plan_dxy_blocks(win, n, std::max<size_t>(passes, 1));
+    timer.lap("window table");
+    pgt_dxy_total tot{};
+    std::vector<pgt_dxy_row> out;
+    std::vector<uint32_t> pa, pb2;
+    for (size_t k = 0; k < pl.shard.size(); ++k) {
+        size_t n_own = 0;
+        const bool any = run_dxy_block(pl, k, win, ctx, [&](uint64_t lo, uint64_t n_k, const pgt_win *w, size_t nw, pgt_dxy_row *o) {
+            Piece a, b;
+            parse_piece(0, lo, lo + n_k, a);
+            parse_piece(1, lo, lo + n_k, b);
+            // the same sites, position for position?
+            const uint32_t *q[2] = {nullptr, nullptr};
+            Piece *pcs[2] = {&a, &b};
+            std::vector<uint32_t> *buf[2] = {&pa, &pb2};
+            for (int i = 0; i < 2; ++i) {
+                if (pcs[i]->m.on_device) {
+                    buf[i]->resize(pcs[i]->rows);
+                    check(pgt_ingest_download(ctx, pcs[i]->m.dev.ing, 1, buf[i]->data(), pcs[i]->rows * sizeof(uint32_t)), ctx);
+                    q[i] = buf[i]->data();
+                } else q[i] = pcs[i]->m.pos.data();
+            }
+            if (std::memcmp(q[0], q[1], a.rows * sizeof(uint32_t)) != 0)
+                die("dxyWindow: the MAF files list different sites; reducing a table in passes (PGT_MAX_RESIDENT_SITES, or inputs larger "
+                    "than the GPU's memory) needs identical site lists");
+            if (a.m.on_device && b.m.on_device) {
+                check(pgt_dxy_reduce_cols(ctx, a.m.dev.col<uint32_t>(1), a.m.dev.col<double>(5), b.m.dev.col<double>(5), a.m.dev.col<int32_t>(6),
+                                          b.m.dev.col<int32_t>(6), a.rows, minind, w, nw, o, nw * sizeof(*o), nullptr), ctx);
+            } else {
+                fetch_columns(a.m);
+                fetch_columns(b.m);
+                check(pgt_dxy_reduce(ctx, q[0], a.m.freq.data(), b.m.freq.data(), a.m.nind.data(), b.m.nind.data(), a.rows, minind, w, nw, o, nullptr), ctx);
+            }
+        }, out, n_own);
+        if (!any) continue;
+        const pgt_win *gw = win.data() + pl.shard[k].win_begin;
+        // chr start end dxy neffective nskip, unless -skip_missing drops the row (dxyWindow.cpp:189-191)
+        write_rows(n_own, longest_name(runs) + 80, [&](size_t i, char *o) -> size_t {
+            if (!(out[i].neff > 0 || !skip_missing)) return 0;
+            return put_row(o, runs.name[gw[i].label_run], {out[i].start, out[i].end}, out[i].sum, {out[i].neff, out[i].nskip});
+        });
+        add_block_rows(tot, out.data() + n_own, out.size() - n_own);
+    }
+    timer.lap("passes");
+    std::fprintf(W == 0 ? stdout : stderr, "%g\t%llu\t%llu\n", tot.sum, (unsigned long long)tot.neff, (unsigned long long)tot.nskip);
+    return true;
 }
 
 int main(int argc, char **argv) {
@@ -273,6 +422,11 @@ int main(int argc, char **argv) {
         open2 = t2.open(argv[argc - 1]);
         other.join();
         timer.lap("open");
+        // inputs larger than the GPU (or PGT_MAX_RESIDENT_SITES): block by block — unless the site lists differ
+        if (open1 && open2)
+            if (const uint64_t resident = resident_limit(t1.begin(), t1.end(), 2 * (4 + 8 + 4), [&] { return device.get(); }, 2))
+                if (dxy_in_passes(device, t1, t2, argv[argc - 2], argv[argc - 1], W, S, minind, fixedsite, skip_missing, chrsize, resident, timer))
+                    finish(timer);
         // large inputs: parse both files on the GPU, one after the other (one context, one thread); a file that
         // cannot be opened is left to the host path below, which reports Pop1's problems first
         if (open1 && open2 && gpu_ingest_wanted(std::min(t1.size(), t2.size()))) {

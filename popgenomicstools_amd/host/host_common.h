@@ -1083,13 +1083,13 @@ inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std:
 // 0: the whole input fits (the usual paths); else the largest number of sites one pass may hold.
 // PGT_MAX_RESIDENT_SITES=<n> forces passes (tests, or a GPU shared with other work).
 template <class GetCtx>
-inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_site_on_gpu, GetCtx &&get_ctx) {
+inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_site_on_gpu, GetCtx &&get_ctx, int texts = 1) {  // texts: files like this one parsed side by side
     if (const char *v = std::getenv("PGT_MAX_RESIDENT_SITES")) {
         const long long lim = std::atoll(v);
         return lim > 0 ? (uint64_t)lim : 0;
     }
     const size_t text_bytes = (size_t)(e - b);
-    if (text_bytes < ((size_t)8 << 30)) return 0;  // far below any MI355X: do not even ask
+    if (text_bytes * (size_t)texts < ((size_t)8 << 30)) return 0;  // far below any MI355X: do not even ask
     size_t free_b = 0, total_b = 0;
     pgt_ctx *ctx = get_ctx();
     check(pgt_dev_memory(ctx, &free_b, &total_b), ctx);
@@ -1097,7 +1097,7 @@ inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_si
     // of < 2 % of them and the rows); bytes per line from the head of the file; a fifth of the memory stays free
     const size_t sample = std::min<size_t>(text_bytes, (size_t)8 << 20);
     const double per_line = (double)sample / (double)std::max<size_t>((size_t)std::count(b, b + sample, '\n'), 1);
-    const double per_site = per_line + 1.1 * (double)bytes_per_site_on_gpu;
+    const double per_site = (double)texts * per_line + 1.1 * (double)bytes_per_site_on_gpu;
     if ((double)text_bytes / per_line * per_site < 0.8 * (double)free_b) return 0;
     return (uint64_t)(0.6 * (double)free_b / per_site);
 }

@@ -2,7 +2,7 @@
 """Randomised differential fuzzer of the device-side ingest at CLI level: random fst / het / MAF files (random
 separators, number formats, CRLF, blank-line stops, missing newline at the end, a bad line now and then) through
 the hosts with PGT_GPU_INGEST=1 and =0 — once more with two or three contexts (PGT_DEVICES=0,0[,0]: the multi-GPU paths, both
-parsers), and for fstWindow / hetWindow in passes (PGT_MAX_RESIDENT_SITES): stdout, stderr and exit code must be identical.
+parsers), and in passes (PGT_MAX_RESIDENT_SITES): stdout, stderr and exit code must be identical.
 usage: python tests/ingest_fuzz.py [seconds] [seed]"""
 import os
 import subprocess
@@ -106,13 +106,16 @@ def main():
                       "files kept in", d)
                 sys.exit(1)
         counts["multi"] = counts.get("multi", 0) + 1
-        if kind != "maf":  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
+        if True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
             limit = int(rng.choice([1, 70000, 150000]))
             env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))
             if rng.random() < 0.5:
-                env["PGT_DEVICES"] = devs  # the blocks go round the contexts
+                env["PGT_DEVICES"] = devs  # fst / het: the blocks go round the contexts (dxyWindow: the first one)
             c = subprocess.run(cmd, capture_output=True, env=env, timeout=120)
             ok = (c.returncode, c.stderr) == (a.returncode, a.stderr) and (c.stdout == a.stdout if a.returncode == 0 else True)
+            if not ok and kind == "maf" and b"different sites" in c.stderr and a.returncode == 0:
+                ok = True  # the same runs with other positions: the passes refuse what the resident host merge accepts
+                counts["refused"] = counts.get("refused", 0) + 1
             if not ok:
                 print("MISMATCH (PGT_MAX_RESIDENT_SITES=%d)" % limit, cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:], "files kept in", d)
                 sys.exit(1)

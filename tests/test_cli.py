@@ -615,6 +615,76 @@ def test_dxy_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, orac
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_dxy_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
+    """dxyWindow with PGT_MAX_RESIDENT_SITES: both MAF texts are scanned for runs and row marks, then reduced block by block
+    (the text of a block's rows of both files -> device parser -> reduce -> print; base-pair windows after one extra pass over
+    file 1 for the positions), the genome-wide line from the blocks' 65536-site rows.  stdout, stderr and the exit code are
+    the resident run's: known answers, 3 * 10^6-site files in every mode and at several limits, a bad line in either file;
+    files whose site lists differ run through the resident path (same output), position-only differences are refused."""
+    import synth
+
+    def passes(cmd, limit):
+        return run(cmd, env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit)))
+
+    k = helpers.load_golden("dxy_kat.json")
+    m1, m2, sz = tmp_path / "p1.mafs.gz", tmp_path / "p2.mafs", tmp_path / "sizes.txt"
+    _write_maf(m1, k["header"], k["pop1"], True)
+    _write_maf(m2, k["header"], k["pop2"])
+    sz.write_text("".join(f"{c}\t{n}\n" for c, n in k["sizes"]))
+    for c in k["cases"]:
+        cmd = [hosts["dxyWindow"], "-winsize", str(c["winsize"]), "-stepsize", str(c["stepsize"]),
+               "-minind", str(k["minind"]), "-fixedsite", str(c["fixedsite"]), "-skip_missing", str(c["skip_missing"])]
+        if not c["fixedsite"]:
+            cmd += ["-sizefile", str(sz)]
+        r = passes(cmd + [str(m1), str(m2)], 1)
+        assert r.returncode == 0 and r.stdout == c["stdout"] and r.stderr == c["stderr"], (c, r.stderr)
+    sub = [row for i, row in enumerate(k["pop2"]) if i != 1]  # pop2 lacks one site of pop1: the resident path's host merge
+    _write_maf(m2, k["header"], sub)
+    cmd = [hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-minind", "2", "-fixedsite", "1", str(m1), str(m2)]
+    one, r = run(cmd), passes(cmd, 1)
+    assert one.returncode == 0 and (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr)
+    moved = [list(row) for row in k["pop2"]]  # the same number of sites per chromosome, one position differs
+    assert moved[0][0] == moved[1][0] and moved[1][1] - 1 > moved[0][1]
+    moved[1][1] -= 1
+    _write_maf(m2, k["header"], moved)
+    r = passes(cmd, 1)
+    assert r.returncode == 255 and "different sites" in r.stderr
+    rng = np.random.default_rng(123)
+    n = 3_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 6, equal=False)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    f1, f2 = tmp_path / "big1.mafs", tmp_path / "big2.mafs"
+    oracle.write_maf_text(str(f1), chr_ids, pos, p1, n1)
+    oracle.write_maf_text(str(f2), chr_ids, pos, p2, n2)
+    ends = np.cumsum(np.diff(np.concatenate(([0], np.flatnonzero(np.diff(chr_ids)) + 1, [n])))) - 1
+    sz.write_text("".join(f"chr{c + 1}\t{int(pos[e]) + 777}\n" for c, e in enumerate(ends)))
+    modes = [["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-fixedsite", "1"],
+             ["-winsize", "20000", "-stepsize", "100", "-minind", "5", "-fixedsite", "1", "-skip_missing", "1"],
+             ["-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-sizefile", str(sz)],
+             ["-winsize", "1000000", "-stepsize", "2000", "-minind", "3", "-sizefile", str(sz)],
+             ["-winsize", "0", "-fixedsite", "1", "-minind", "5"]]
+    for opts in modes:
+        cmd = [hosts["dxyWindow"]] + opts + [str(f1), str(f2)]
+        one = run(cmd)
+        assert one.returncode == 0
+        timed = run(cmd, env=dict(os.environ, PGT_MAX_RESIDENT_SITES="300000", PGT_HOST_TIMING="1"))
+        assert "scan runs" in timed.stderr and "passes" in timed.stderr and timed.stdout == one.stdout
+        for limit in (1, 300_000, 1_500_000, 10**9):
+            r = passes(cmd, limit)
+            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (opts, limit, r.stderr[-300:])
+    # a bad line in a later block of file 2, then of file 1 as well (Pop1's message first where both are in one block)
+    lines2 = f2.read_text().splitlines(True)
+    bad2 = tmp_path / "bad2.mafs"
+    bad2.write_text("".join(lines2[:2_000_000]) + lines2[2_000_000].rstrip("\n") + "x\n" + "".join(lines2[2_000_001:]))
+    cmd = [hosts["dxyWindow"]] + modes[0] + [str(f1), str(bad2)]
+    one, r = run(cmd), passes(cmd, 300_000)
+    assert one.returncode == 255 and "line 2000001 " in one.stderr and (r.returncode, r.stderr) == (255, one.stderr)
+    full = run([hosts["dxyWindow"]] + modes[0] + [str(f1), str(f2)]).stdout
+    assert r.stdout and full.startswith(r.stdout) and len(r.stdout) < len(full)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     """PGT_MAX_RESIDENT_SITES=<n>: the table is reduced block by block (first scan of the text on the host for runs and
     row marks, then per block: text of its rows -> GPU parser -> reduce -> print), as for an input larger than the GPU's
