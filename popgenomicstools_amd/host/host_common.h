@@ -1082,6 +1082,14 @@ inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std:
 
 // 0: the whole input fits (the usual paths); else the largest number of sites one pass may hold.
 // PGT_MAX_RESIDENT_SITES=<n> forces passes (tests, or a GPU shared with other work).
+// the decision itself: the device parser holds the text and the columns of what it parses at once (the reduce after it:
+// columns, a tree of < 2 % of them and the rows); resident if that needs less than 80 % of the free memory, else passes of
+// what fits 60 % of it
+inline uint64_t resident_limit_for(size_t text_bytes, double bytes_per_line, size_t bytes_per_site_on_gpu, size_t free_bytes, int texts) {
+    const double per_site = (double)texts * bytes_per_line + 1.1 * (double)bytes_per_site_on_gpu;
+    if ((double)text_bytes / bytes_per_line * per_site < 0.8 * (double)free_bytes) return 0;
+    return std::max<uint64_t>((uint64_t)(0.6 * (double)free_bytes / per_site), 1);
+}
 template <class GetCtx>
 inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_site_on_gpu, GetCtx &&get_ctx, int texts = 1) {  // texts: files like this one parsed side by side
     if (const char *v = std::getenv("PGT_MAX_RESIDENT_SITES")) {
@@ -1093,13 +1101,9 @@ inline uint64_t resident_limit(const char *b, const char *e, size_t bytes_per_si
     size_t free_b = 0, total_b = 0;
     pgt_ctx *ctx = get_ctx();
     check(pgt_dev_memory(ctx, &free_b, &total_b), ctx);
-    // the device parser holds the text and the columns of what it parses at once (the reduce after it: columns, a tree
-    // of < 2 % of them and the rows); bytes per line from the head of the file; a fifth of the memory stays free
-    const size_t sample = std::min<size_t>(text_bytes, (size_t)8 << 20);
+    const size_t sample = std::min<size_t>(text_bytes, (size_t)8 << 20);  // bytes per line from the head of the file
     const double per_line = (double)sample / (double)std::max<size_t>((size_t)std::count(b, b + sample, '\n'), 1);
-    const double per_site = (double)texts * per_line + 1.1 * (double)bytes_per_site_on_gpu;
-    if ((double)text_bytes / per_line * per_site < 0.8 * (double)free_b) return 0;
-    return (uint64_t)(0.6 * (double)free_b / per_site);
+    return resident_limit_for(text_bytes, per_line, bytes_per_site_on_gpu, free_b, texts);
 }
 
 // The passes.  parse_and_reduce(ctx, piece_begin, piece_end, first_row /*global*/, rows_in_piece, win /*rebased*/, n_win, out, error)

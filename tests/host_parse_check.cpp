@@ -11,7 +11,8 @@
 //   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
 //      per piece and stitched with Runs::add are the runs of the whole text;
 //   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks;
-//   7. HostBuf (huge-page mappings for columns, rows and inflated text): alignment, size, every byte writable.
+//   7. HostBuf (huge-page mappings for columns, rows and inflated text): alignment, size, every byte writable;
+//   8. resident_limit_for: which inputs are reduced in passes, and of how many sites.
 #include <dirent.h>
 
 #include <cinttypes>
@@ -392,6 +393,16 @@ int main(int argc, char **argv) {
         c.alloc((size_t)3 << 20);  // 24 MiB
         c[((size_t)3 << 20) - 1] = 2.5;
         CHECK(c.data()[((size_t)3 << 20) - 1] == 2.5);
+    }
+    {   // 8. resident or in passes (resident_limit_for): 10^9 fstWindow lines fit a 288-GB MI355X, 10^10 do not
+        const size_t free_b = (size_t)280 << 30;
+        CHECK(resident_limit_for((size_t)33e9, 33.0, 20, free_b, 1) == 0);           // 33 GB of text + 22 GB of columns
+        const uint64_t lim = resident_limit_for((size_t)330e9, 33.0, 20, free_b, 1);  // 10^10 lines
+        CHECK(lim > 2000000000ull && lim < 4000000000ull);
+        CHECK((double)lim * (33.0 + 22.0) < 0.61 * (double)free_b);
+        CHECK(resident_limit_for((size_t)105e9, 35.0, 32, free_b, 2) > 0);           // an all-sites MAF pair of a 3-Gb genome
+        CHECK(resident_limit_for((size_t)35e9, 35.0, 32, free_b, 2) == 0);
+        CHECK(resident_limit_for((size_t)1 << 40, 8.0, 20, (size_t)1 << 20, 1) >= 1);  // never 0 when passes are needed
     }
     std::printf(fails ? "host_parse_check: %d FAILURES\n" : "host_parse_check: all equal (%d)\n", fails);
     return fails ? 1 : 0;
