@@ -921,6 +921,17 @@ inline std::vector<const char *> cut_at_lines(const char *b, const char *e, size
     return cut;
 }
 
+// The last line of [b,e) holds nothing but blanks (or nothing at all): for the parser of that piece the data simply ends
+// there, but it ends there for the pieces behind it as well
+inline bool ends_with_blank_line(const char *b, const char *e) {
+    if (e == b) return false;
+    const char *p = e;
+    if (p[-1] == '\n') --p;
+    for (; p > b && p[-1] != '\n'; --p)
+        if (p[-1] != ' ' && p[-1] != '\t' && p[-1] != '\r') return false;
+    return true;
+}
+
 // Parse one file on all devices: piece k on device k.  true: `pieces` (one per device that got data, in file order) and
 // `runs` (stitched at the seams) describe the table, *n_rows its length; false: some piece was refused by the device
 // parser (too many irregular lines) — parse on the host.  Text errors die with the host parser's message.
@@ -960,7 +971,7 @@ inline bool ingest_on_devices(DeviceOpener &device, const char *b, const char *e
         for (size_t r = 0; r < n_runs; ++r) runs.add(cut[k] + off[r], cut[k] + off[r] + nlen[r], len[r]);  // add() merges a run that continues across the seam
         pieces.push_back(DevicePiece{device.get(k), ing[k], row, rows});
         row += rows;
-        const bool stopped = pgt_ingest_blank_before_end(ing[k]) != 0;
+        const bool stopped = pgt_ingest_blank_before_end(ing[k]) != 0 || ends_with_blank_line(cut[k], cut[k + 1]);
         ing[k] = nullptr;
         if (stopped) break;  // a blank line ends the data (fstWindow.cpp:125): the pieces behind it are not part of the table
     }

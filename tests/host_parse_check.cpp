@@ -345,6 +345,14 @@ int main(int argc, char **argv) {
             CHECK(stitched.name == whole.name && stitched.len == whole.len);
         }
     }
+    {   // 5b. a piece whose LAST line is blank ends the data for the pieces behind it (found by tests/ingest_fuzz.py: the device
+        //     parser of such a piece sees nothing unusual)
+        CHECK(!ends_with_blank_line("", ""));
+        const char *yes[] = {"\n", " \n", "c 1 2\n\n", "c 1 2\n \t\r\n", "c 1 2\n  ", "c 1 2\n\r\n"};
+        const char *no[] = {"c 1 2\n", "c 1 2", "\nc 1 2\n", " \nc 1 2", "c 1 2\nx \n"};
+        for (const char *t : yes) CHECK(ends_with_blank_line(t, t + std::strlen(t)));
+        for (const char *t : no) CHECK(!ends_with_blank_line(t, t + std::strlen(t)));
+    }
     {   // 6. the first scan of the passes mode (scan_runs_and_marks): rows, runs, the end of the data and a mark at every 65536th row
         for (int trial = 0; trial < 6; ++trial) {
             std::string text;

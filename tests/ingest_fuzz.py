@@ -64,6 +64,23 @@ def make_file(rng, path, kind):
     return n
 
 
+def keep_failure(d, cmd, runs):
+    """the inputs and every run's output of a mismatch -> gpurun_out/fuzz_fail/ (comes back from the GPU box)"""
+    import shutil
+    out = os.path.join(ROOT, "gpurun_out", "fuzz_fail")
+    os.makedirs(out, exist_ok=True)
+    for fn in os.listdir(d):
+        if os.path.getsize(os.path.join(d, fn)) < (48 << 20):
+            shutil.copy(os.path.join(d, fn), out)
+    with open(os.path.join(out, "cmd.txt"), "w") as fh:
+        fh.write(" ".join(cmd) + "\n")
+    for name, r in runs.items():
+        with open(os.path.join(out, name + ".stdout"), "wb") as fh:
+            fh.write(r.stdout)
+        with open(os.path.join(out, name + ".stderr"), "wb") as fh:
+            fh.write(r.stderr)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -89,7 +106,19 @@ def main():
                 del rng2
             else:
                 make_file(rng, f2, "maf")
-            cmd = [os.path.join(BIN, "dxyWindow"), "-winsize", str(W), "-stepsize", str(S), "-minind", "5", "-fixedsite", "1", f1, f2]
+            mode = int(rng.integers(0, 4))  # fixed-site windows, base-pair windows (two sizes of them), the global line only
+            opts = ["-minind", str(int(rng.integers(1, 12))), "-skip_missing", str(int(rng.integers(0, 2)))]
+            if mode == 0:
+                opts += ["-winsize", str(W), "-stepsize", str(S), "-fixedsite", "1"]
+            elif mode == 3:
+                opts += ["-winsize", "0", "-fixedsite", "1"]
+            else:
+                fs = os.path.join(d, "sizes.txt")
+                with open(fs, "w") as fh:  # every chromosome name the generator can produce, longer than any position it writes
+                    fh.write("".join("c%d\t%d\n" % (c, 200000 * 60 + 1000 + c) for c in range(6)))
+                Wb = int(rng.choice([W * 30, W * 3000]))
+                opts += ["-winsize", str(Wb), "-stepsize", str(max(1, Wb // int(rng.integers(1, 6)))), "-sizefile", fs]
+            cmd = [os.path.join(BIN, "dxyWindow")] + opts + [f1, f2]
         else:
             f = os.path.join(d, kind + ".txt")
             make_file(rng, f, kind)
@@ -104,6 +133,9 @@ def main():
             if (c.returncode, c.stdout, c.stderr) != (a.returncode, a.stdout, a.stderr):
                 print("MISMATCH (PGT_DEVICES=%s, PGT_GPU_INGEST=%s)" % (devs, m), cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:],
                       "files kept in", d)
+                again = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST=m, PGT_DEVICES=devs), timeout=120)
+                print("the same run again:", "as before" if again.stdout == c.stdout else ("as the single-device run" if again.stdout == a.stdout else "a third output"))
+                keep_failure(d, cmd, {"single": a, "multi": c, "multi_again": again})
                 sys.exit(1)
         counts["multi"] = counts.get("multi", 0) + 1
         if True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
