@@ -6,14 +6,15 @@ kernel are worth, so two builds are only comparable when their launches alternat
 libraries are loaded side by side (ctypes handles are per path), each gets its own context on GPU 0, and every
 configuration is measured A B B A ... on the same columns, tables and workspace.
 
-  python tools/lib_ab.py tools/_ab/libpgtwin_before.so [sites=1e8] [rounds=10]
+  python tools/lib_ab.py tools/_ab/libpgtwin_before.so [sites=1e8] [rounds=10] [calls per measurement=1]
 
 A = the library named on the command line (e.g. the previous commit's, built in a scratch worktree:
 `git worktree add gpurun_out/wt HEAD~1`, build there, copy the .so to tools/_ab/ — *.so files are not committed but
 travel with gpurun), B = the tree's own.  Reported: median build-phase and whole-step times of each and the median of
-the paired differences.  Every launch here starts on an idle GPU (a synchronise after each call, so that the two
-libraries never overlap): the absolute rates read 2-5 points below those of back-to-back launches (bench.py,
-measure_configs.py); only the difference between A and B is the result."""
+the paired differences.  With one call per measurement every launch starts on an idle GPU (a synchronise after each
+call): the absolute rates then read 2-5 points below those of back-to-back launches (bench.py, measure_configs.py) and only
+the difference between A and B is the result; with several calls per measurement a library's launches follow each other
+as in bench.py, the libraries still alternate."""
 import os
 import sys
 
@@ -39,10 +40,29 @@ def one(ctx, fn):
     return ctx.last_kernel_ms()[0], e0.elapsed_time(e1)
 
 
+BURST = 1  # calls per measurement; > 1 (fourth argument): back-to-back launches of one library, as bench.py issues them
+
+
+def burst(ctx, fn):
+    """BURST calls without a synchronise between them -> (build phase ms of the last call, whole step ms averaged)"""
+    if BURST == 1:
+        return one(ctx, fn)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(ctx)  # the first call starts on an idle GPU: not timed
+    e0.record()
+    for _ in range(BURST):
+        fn(ctx)
+    e1.record()
+    torch.cuda.synchronize()
+    return ctx.last_kernel_ms()[0], e0.elapsed_time(e1) / BURST
+
+
 def main():
+    global BURST
     old = os.path.abspath(sys.argv[1])
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    BURST = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     dev = torch.device("cuda", 0)
     ctx_b = pgt.Context(0)  # the tree's library
     _lib._lib, _lib.LIB_PATH = None, old
@@ -65,21 +85,22 @@ def main():
         ("hetWindow", 1, lambda c: c.het_reduce_dev(pos, g1, win, out=out, tree=tree)),
         ("dxy + het x2 fused", 26, lambda c: c.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)),
     ]
-    print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A\n")
-    print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms |")
-    print("|---|---|---|---|---|---|---|---|")
+    print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A, {BURST} call(s) per measurement\n")
+    print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms | step B - A paired |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for name, bps, fn in configs:
         for c in (ctx_a, ctx_b, ctx_a, ctx_b):
             one(c, fn)
-        ra, rb, diff = [], [], []
+        ra, rb, diff, sdiff = [], [], [], []
         for _ in range(rounds):
-            a1, b1, b2, a2 = one(ctx_a, fn), one(ctx_b, fn), one(ctx_b, fn), one(ctx_a, fn)
+            a1, b1, b2, a2 = burst(ctx_a, fn), burst(ctx_b, fn), burst(ctx_b, fn), burst(ctx_a, fn)
             ra += [a1, a2]
             rb += [b1, b2]
             diff += [b1[0] - a1[0], b2[0] - a2[0]]
+            sdiff += [b1[1] - a1[1], b2[1] - a2[1]]
         ma, mb = np.median([x[0] for x in ra]), np.median([x[0] for x in rb])
         print(f"| {name} | {ma:.4f} | {mb:.4f} | {np.median(diff) * 1e3:+.1f} us | {bps * n / ma / 8e7:.1f} | {bps * n / mb / 8e7:.1f} | "
-              f"{np.median([x[1] for x in ra]):.4f} | {np.median([x[1] for x in rb]):.4f} |")
+              f"{np.median([x[1] for x in ra]):.4f} | {np.median([x[1] for x in rb]):.4f} | {np.median(sdiff) * 1e3:+.1f} us |")
 
 
 if __name__ == "__main__":
