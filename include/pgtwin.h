@@ -338,7 +338,7 @@ int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1,
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
 uint64_t pgt_ingest_rows(const pgt_ingest *ing);
-/* 1 when the data ended at a blank line BEFORE the last line of `text` (the tools stop reading there, fstWindow.cpp:125):
+/* 1 when the data ended at a blank line of `text`, be it its last line (the tools stop reading there, fstWindow.cpp:125):
  * a caller that hands consecutive pieces of one file to several GPUs must drop the pieces behind such a one. */
 int pgt_ingest_blank_before_end(const pgt_ingest *ing);
 int64_t pgt_ingest_bad_line(const pgt_ingest *ing);

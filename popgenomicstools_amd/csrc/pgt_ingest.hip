@@ -362,7 +362,7 @@ struct pgt_ingest {
     int device = 0;
     uint64_t rows = 0;
     int64_t bad_line = -1;
-    bool blank_before_end = false;  // the data ended at a blank line that is not the (empty) last line of the text
+    bool blank_before_end = false;  // the data ended at a blank line (possibly the last line of the text)
     int n_tokens = 0;
     uint8_t tok[kMaxTokens] = {};
     void *col[kMaxTokens] = {};
@@ -475,7 +475,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
         return ingest_fail(err, PGT_EDOMAIN, "pgt_ingest_text: a line longer than 64 KiB, or more than 2^20 chromosome runs or irregular "
                                              "lines: parse this input on the host");
     const uint64_t n_rows = std::min<uint64_t>(n_lines, cnt.first_empty);
-    ing->blank_before_end = cnt.first_empty != ~0ull && cnt.first_empty + 1 < n_lines;
+    ing->blank_before_end = cnt.first_empty != ~0ull;  // also when it is the text's last line: a caller's next piece lies behind it
     std::vector<ListEntry> runs(cnt.n_runs), slow(cnt.n_slow);
     if (cnt.n_runs)
         if (int rc = hip(hipMemcpy(runs.data(), druns.p, runs.size() * sizeof(ListEntry), hipMemcpyDeviceToHost), "run list")) return rc;
