@@ -212,6 +212,21 @@ def test_download_is_bounded_by_the_column(ctx):
     ing.free()
 
 
+def test_blank_line_flag_for_callers_that_cut_a_text_into_pieces(ctx):
+    """pgt_ingest_blank_before_end: 1 whenever the data ended at a blank line of the text — also when that is its LAST
+    line (a host that hands consecutive pieces to several GPUs must drop the pieces behind it; tests/ingest_fuzz.py found
+    the case where the blank line closed a piece) — and 0 for a text that simply ends, with or without a newline."""
+    lib = ctx._lib
+    cases = [(b"c0  133  1\n \n", 1, 1), (b"c0  133  1\n\n", 1, 1), (b"c0  133  1\n ", 1, 1), (b"c0  133  1\n \t\r\n", 1, 1),
+             (b"c0  133  1\n", 1, 0), (b"c0  133  1", 1, 0), (b"c0  133  1\r\n", 1, 0),
+             (b"c0  133  1\n \nc1  5  1\n", 1, 1), (b" \nc1 5 1\n", 0, 1), (b"\n", 0, 1),
+             (b"c0  48  -9\nc0  62  1\nc0  110  3\n", 3, 0)]
+    for text, rows, flag in cases:
+        ing = ctx.ingest_text(text, HET)
+        assert (ing.rows, int(lib.pgt_ingest_blank_before_end(ing._h)), ing.bad_line) == (rows, flag, -1), text
+        ing.free()
+
+
 def test_absurdly_long_lines_are_refused_not_walked(ctx):
     """A line of 300 KB is not one of the tools' tables: the device path refuses the input (PGT_EDOMAIN) instead
     of letting one lane walk through it; the hosts then parse it themselves."""
