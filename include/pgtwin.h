@@ -294,6 +294,8 @@ int pgt_dev_alloc(pgt_ctx *ctx, size_t bytes, void **dev_ptr);
 /* free and total memory of ctx's device in bytes (the hosts decide with it whether a table must be reduced in passes) */
 int pgt_dev_memory(pgt_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr);
+/* host memory -> a buffer of ctx's device (synchronous) */
+int pgt_dev_upload(pgt_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src, size_t bytes);
 
 /* ---- device-side text ingest ------------------------------------------------ */
@@ -337,6 +339,13 @@ int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1,
 /* device column of token `token` -> host (bytes <= rows * element size, else PGT_EARG) */
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);
+/* The same, with room for `rows_in_front` more rows BEFORE the parsed ones in every column: a caller that parses the head
+ * of a text itself (the shipped hosts do, beside HIP start-up) uploads its rows there (pgt_dev_upload to
+ * pgt_ingest_column_base) and has one contiguous column without a copy.  pgt_ingest_column still points at the first
+ * parsed row, pgt_ingest_rows counts the parsed rows only. */
+int pgt_ingest_text_behind(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens,
+                           uint64_t rows_in_front, pgt_ingest **out);
+void *pgt_ingest_column_base(const pgt_ingest *ing, int token);
 uint64_t pgt_ingest_rows(const pgt_ingest *ing);
 /* 1 when the data ended at a blank line of `text`, be it its last line (the tools stop reading there, fstWindow.cpp:125):
  * a caller that hands consecutive pieces of one file to several GPUs must drop the pieces behind such a one. */

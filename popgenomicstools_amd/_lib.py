@@ -45,7 +45,7 @@ SYMBOLS = [
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
     "pgt_tree_bytes", "pgt_fst_reduce_dev", "pgt_het_reduce_dev", "pgt_dxy_reduce_dev",
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
-    "pgt_dev_alloc", "pgt_dev_free", "pgt_dev_copy", "pgt_dev_memory", "pgt_set_typical_window", "pgt_table_hints", "pgt_ingest_blank_before_end",
+    "pgt_dev_alloc", "pgt_dev_free", "pgt_dev_copy", "pgt_dev_upload", "pgt_dev_memory", "pgt_ingest_text_behind", "pgt_ingest_column_base", "pgt_set_typical_window", "pgt_table_hints", "pgt_ingest_blank_before_end",
     "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read", "pgt_rowbuf_fill",
     "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
     "pgt_wintab_sites", "pgt_wintab_size", "pgt_wintab_first", "pgt_wintab_device", "pgt_wintab_free",
@@ -120,6 +120,10 @@ def load() -> C.CDLL:
     lib.pgt_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.pgt_dev_free.argtypes = [vp, vp]
     lib.pgt_dev_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    lib.pgt_dev_upload.argtypes = [vp, vp, vp, sz]
+    lib.pgt_ingest_text_behind.argtypes = [vp, vp, sz, vp, i32, u64, C.POINTER(vp)]
+    lib.pgt_ingest_column_base.restype = vp
+    lib.pgt_ingest_column_base.argtypes = [vp, i32]
     lib.pgt_set_typical_window.argtypes = [vp, u64]
     lib.pgt_table_hints.argtypes = [vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.pgt_dev_copy.argtypes = [vp, vp, vp, vp, sz]

@@ -396,7 +396,13 @@ int pgt_extreme_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *scor
 
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out) {
     PGT_USE_DEVICE(ctx);
-    return ingest_text(ctx->device, text, len, tokens, n_tokens, out, &ctx->error);
+    return ingest_text(ctx->device, text, len, tokens, n_tokens, 0, out, &ctx->error);
+}
+
+int pgt_ingest_text_behind(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, uint64_t rows_in_front,
+                           pgt_ingest **out) {
+    PGT_USE_DEVICE(ctx);
+    return ingest_text(ctx->device, text, len, tokens, n_tokens, rows_in_front, out, &ctx->error);
 }
 
 /* ---------------- multi-GPU row exchange ---------------- */
@@ -489,6 +495,13 @@ int pgt_dev_free(pgt_ctx *ctx, void *dev_ptr) {
     PGT_USE_DEVICE(ctx);
     if (!dev_ptr) return PGT_OK;
     return hip_check(ctx, hipFree(dev_ptr), "pgt_dev_free: hipFree");
+}
+
+int pgt_dev_upload(pgt_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    PGT_USE_DEVICE(ctx);
+    if (bytes == 0) return PGT_OK;
+    if (!dev_dst || !host_src) return ctx_fail(ctx, PGT_EARG, "pgt_dev_upload: NULL argument");
+    return hip_check(ctx, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice), "pgt_dev_upload: hipMemcpy");
 }
 
 int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src, size_t bytes) {

@@ -365,7 +365,9 @@ struct pgt_ingest {
     bool blank_before_end = false;  // the data ended at a blank line (possibly the last line of the text)
     int n_tokens = 0;
     uint8_t tok[kMaxTokens] = {};
-    void *col[kMaxTokens] = {};
+    void *col[kMaxTokens] = {};   // first PARSED row of every column
+    void *base[kMaxTokens] = {};  // the allocation: `front` rows of room before col[k] (pgt_ingest_text_behind), else == col[k]
+    uint64_t front = 0;
     std::vector<uint64_t> run_len, name_off;
     std::vector<uint32_t> name_len;
 };
@@ -386,7 +388,7 @@ int ingest_fail(std::string *err, int code, const std::string &msg) {
 
 namespace pgt {
 
-int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err) {
+int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, uint64_t front, pgt_ingest **out, std::string *err) {
     if (!out || (len && !text) || !tokens || n_tokens < 2 || n_tokens > kMaxTokens || tokens[0] != PGT_TOK_CHR)
         return ingest_fail(err, PGT_EARG, "pgt_ingest_text: bad argument (the first token must be PGT_TOK_CHR, 2..8 tokens)");
     for (int k = 1; k < n_tokens; ++k)
@@ -407,11 +409,12 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     };
     std::unique_ptr<pgt_ingest> ing(new pgt_ingest);
     ing->device = device;
+    ing->front = front;
     ing->n_tokens = n_tokens;
     std::memcpy(ing->tok, tokens, (size_t)n_tokens);
     struct FreeCols {  // columns are handed over only on success
         pgt_ingest *g;
-        ~FreeCols() { if (g) for (auto &c : g->col) if (c) { (void)hipFree(c); c = nullptr; } }
+        ~FreeCols() { if (g) for (int k = 0; k < kMaxTokens; ++k) if (g->base[k]) { (void)hipFree(g->base[k]); g->base[k] = g->col[k] = nullptr; } }
     } free_cols{ing.get()};
     if (len == 0) {
         free_cols.g = nullptr;
@@ -454,7 +457,8 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     for (int k = 0; k < n_tokens; ++k) {
         spec.tok[k] = tokens[k];
         if (const size_t eb = elem_bytes(tokens[k])) {
-            if (int rc = hip(hipMalloc(&ing->col[k], n_lines * eb + 16), "alloc column")) return rc;
+            if (int rc = hip(hipMalloc(&ing->base[k], (front + n_lines) * eb + 16), "alloc column")) return rc;
+            ing->col[k] = static_cast<char *>(ing->base[k]) + front * eb;
             cols.col[k] = ing->col[k];
         }
     }
@@ -560,6 +564,9 @@ int pgt_ingest_blank_before_end(const pgt_ingest *g) { return g && g->blank_befo
 void *pgt_ingest_column(const pgt_ingest *g, int token) {
     return g && token >= 0 && token < g->n_tokens ? g->col[token] : nullptr;
 }
+void *pgt_ingest_column_base(const pgt_ingest *g, int token) {
+    return g && token >= 0 && token < g->n_tokens ? g->base[token] : nullptr;
+}
 size_t pgt_ingest_runs(const pgt_ingest *g, const uint64_t **run_len, const uint64_t **name_off, const uint32_t **name_len) {
     if (!g) return 0;
     if (run_len) *run_len = g->run_len.data();
@@ -571,7 +578,7 @@ void pgt_ingest_free(pgt_ingest *g) {
     if (!g) return;
     int saved = -1;
     const bool sw = hipGetDevice(&saved) == hipSuccess && saved != g->device && hipSetDevice(g->device) == hipSuccess;
-    for (auto &c : g->col)
+    for (auto &c : g->base)
         if (c) (void)hipFree(c);
     if (sw) (void)hipSetDevice(saved);
     delete g;

@@ -190,7 +190,7 @@ int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_
 int launch_fill_pattern(uint64_t *words, uint64_t n_words, uint64_t seed, void *stream, std::string *err);
 
 // pgt_ingest.hip: text -> device columns + chromosome runs (synchronous, default stream of `device`)
-int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out, std::string *err);
+int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, uint64_t front, pgt_ingest **out, std::string *err);
 size_t ingest_column_bytes(const pgt_ingest *ing, int token);  // rows * element size of the token's column (0: no column)
 
 int init_kernels(std::string *err);     // pgt_kernels.hip: one-time kernel attributes (called by pgt_open)

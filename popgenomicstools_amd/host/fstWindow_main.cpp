@@ -89,7 +89,17 @@ int main(int argc, char **argv) {
                 });
             finish(timer);
         }
-        if (gpu_ingest_wanted(text.size())) {
+        bool parsed = false;  // by the hybrid path, into the host table (the data ended inside its head)
+        if (gpu_ingest_wanted(text.size()) && !multi) {  // large inputs: head on the host beside HIP start-up, tail on the GPU
+            const int h = ingest_hybrid(device, text.begin(), text.end(), spec, 4, what, argv[1], tab,
+                                        [](decltype(tab) &t) {
+                                            return std::vector<HybridColumn>{{1, sizeof(uint32_t), t.pos.data()}, {2, sizeof(double), t.a.data()},
+                                                                             {3, sizeof(double), t.b.data()}};
+                                        }, dtab, runs, &n, timer);
+            on_device = h == 1;
+            parsed = h == 2;
+        }
+        if (gpu_ingest_wanted(text.size()) && !on_device && !parsed) {
             pgt_ctx *c = device.get();
             timer.lap("wait for HIP");
             if (multi) {
@@ -100,7 +110,7 @@ int main(int argc, char **argv) {
             }
             timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
         }
-        if (!on_device) {
+        if (!on_device && !parsed) {
             n = parse_table(text.begin(), text.end(), tab, runs, what, argv[1], 1);
             timer.lap("parse");
             if (cache.enabled()) {

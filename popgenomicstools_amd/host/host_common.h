@@ -785,19 +785,23 @@ inline bool gpu_ingest_wanted(size_t text_bytes) {
 struct DeviceTable {
     pgt_ingest *ing = nullptr;
     size_t n = 0;
+    bool from_base = false;  // the table starts in the room in front of the parsed rows (ingest_hybrid: the head parsed on the host)
     DeviceTable() = default;
     DeviceTable(const DeviceTable &) = delete;
     DeviceTable &operator=(const DeviceTable &) = delete;
     ~DeviceTable() { if (ing) pgt_ingest_free(ing); }
-    template <class T> T *col(int token) const { return static_cast<T *>(pgt_ingest_column(ing, token)); }
+    template <class T> T *col(int token) const { return static_cast<T *>(from_base ? pgt_ingest_column_base(ing, token) : pgt_ingest_column(ing, token)); }
 };
 // true: `tab` and `runs` hold the parsed table (errors in the text die here with the host parser's message);
 // false: the input has too many irregular lines for the device path — parse it on the host
 // error: receives the message about a bad line instead of the exit (two files parsed side by side: the caller reports
 // the first file's problem first, whichever thread met its problem first)
+// rows_in_front: room for that many rows before the parsed ones in every column (pgt_ingest_text_behind)
 inline bool ingest_on_device(pgt_ctx *ctx, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what,
-                             const char *path, size_t first_line_no, DeviceTable &tab, Runs &runs, std::string *error = nullptr) {
-    const int rc = pgt_ingest_text(ctx, b, (size_t)(e - b), spec, n_tokens, &tab.ing);
+                             const char *path, size_t first_line_no, DeviceTable &tab, Runs &runs, std::string *error = nullptr,
+                             uint64_t rows_in_front = 0) {
+    const int rc = rows_in_front ? pgt_ingest_text_behind(ctx, b, (size_t)(e - b), spec, n_tokens, rows_in_front, &tab.ing)
+                                 : pgt_ingest_text(ctx, b, (size_t)(e - b), spec, n_tokens, &tab.ing);
     if (rc == PGT_EDOMAIN) return false;
     check(rc, ctx);
     const int64_t bad = pgt_ingest_bad_line(tab.ing);
@@ -1026,6 +1030,75 @@ void reduce_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, ui
             for (void *d : dcols) check(pgt_dev_free(ctx, d), ctx);
         });
     for (auto &t : th) t.join();
+}
+
+// ---- large inputs, one GPU: the host parses the head of the text while HIP starts, the GPU the rest --------------------------
+// HIP start-up (70-260 ms) is dead time for the device parser, and what the host parser needs for 1-2 GB of text (14 GB/s
+// on this box's share of cores).  So from 1.25 GiB on the text is cut at a line start near 1 GiB: the host threads parse
+// the head into huge-page columns beside HIP start-up and the GPU parses the tail behind room for the head's rows
+// (pgt_ingest_text_behind), into which the head's columns are then uploaded (20 B per line instead of 33 B of text): one
+// contiguous column per field, no copy.  Measured, fstWindow end to end, alternating runs (profiles/r03/hybrid_ingest_ab.txt): 1.65 GB 0.34 -> 0.17-0.25 s,
+// 3.3 GB 0.44 -> 0.30 s, 10 GB 0.69 -> 0.70 s; a head of 2-3 GiB is worse than 1 GiB (its parse then runs beside the
+// upload of the tail and slows it).  PGT_HYBRID_HOST_BYTES=<n> moves the cut (0: off).
+//   0  not taken (small input, switched off, or the device refused the tail): nothing was changed
+//   1  `tab` and `runs` hold the table on the GPU
+//   2  the data ended at a blank line inside the head: `host_tab` (n rows) and `runs` hold it on the host
+struct HybridColumn { int token; size_t elem; const void *host; };  // host: the head's column, valid after the parse
+template <class Table, class HostColumns>
+int ingest_hybrid(DeviceOpener &device, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what, const char *path,
+                  Table &host_tab, HostColumns host_columns, DeviceTable &tab, Runs &runs, size_t *n_rows, PhaseTimer &timer) {
+    size_t host_bytes = (size_t)1 << 30, least = (size_t)5 << 28;  // cut near 1 GiB, inputs from 1.25 GiB on
+    if (const char *v = std::getenv("PGT_HYBRID_HOST_BYTES")) {
+        host_bytes = (size_t)std::max<long long>(std::atoll(v), 0);
+        least = host_bytes + 1;
+    }
+    if (host_bytes == 0 || (size_t)(e - b) < least) return 0;
+    const void *nl = std::memchr(b + host_bytes - 1, '\n', (size_t)(e - (b + host_bytes - 1)));
+    const char *cut = nl ? static_cast<const char *>(nl) + 1 : e;
+    if (cut >= e) return 0;
+    // lines of the head: the tail's messages carry global line numbers
+    size_t head_lines = 0;
+    {
+        const int T = host_threads();
+        const std::vector<const char *> part = cut_at_lines(b, cut, (size_t)T);
+        std::vector<size_t> k(T, 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] { k[t] = (size_t)std::count(part[t], part[t + 1], '\n'); });
+        for (auto &x : th) x.join();
+        for (size_t v : k) head_lines += v;
+    }
+    std::string err_h, err_d;
+    Runs runs_h, runs_d;
+    size_t n_h = 0;
+    std::thread head([&] { n_h = parse_table(b, cut, host_tab, runs_h, what, path, 1, &err_h); });
+    pgt_ctx *ctx = device.get();
+    const bool ok_d = ingest_on_device(ctx, cut, e, spec, n_tokens, what, path, head_lines + 1, tab, runs_d, &err_d, head_lines);
+    head.join();
+    timer.lap("head on the host, tail on the GPU");
+    if (!err_h.empty()) die(err_h);
+    auto drop_tail = [&] {
+        if (tab.ing) pgt_ingest_free(tab.ing);
+        tab.ing = nullptr;
+        tab.n = 0;
+    };
+    if (n_h < head_lines) {  // a blank line in the head: the data ended there
+        drop_tail();
+        runs = runs_h;
+        *n_rows = n_h;
+        return 2;
+    }
+    if (!ok_d) return 0;  // too many irregular lines in the tail: the caller parses everything on the host
+    if (!err_d.empty()) die(err_d);
+    const size_t n = n_h + tab.n;  // n_h == head_lines: the head's rows fill the room in front exactly
+    for (const HybridColumn &c : host_columns(host_tab))
+        check(pgt_dev_upload(ctx, pgt_ingest_column_base(tab.ing, c.token), c.host, n_h * c.elem), ctx);
+    tab.from_base = true;
+    tab.n = n;
+    runs = runs_h;
+    runs.append(runs_d);
+    *n_rows = n;
+    timer.lap("columns joined");
+    return 1;
 }
 
 // ---- a table larger than the GPU: reduced in PASSES (PGT_MAX_RESIDENT_SITES, or by itself when the text would not fit) -----

@@ -138,6 +138,14 @@ def main():
                 keep_failure(d, cmd, {"single": a, "multi": c, "multi_again": again})
                 sys.exit(1)
         counts["multi"] = counts.get("multi", 0) + 1
+        if kind != "maf":  # the head of the text on the host parser, the tail on the GPU, the columns joined there
+            cut = int(rng.integers(1, max(2, os.path.getsize(f) + 2)))
+            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES=str(cut)), timeout=120)
+            if (c.returncode, c.stdout, c.stderr) != (a.returncode, a.stdout, a.stderr):
+                print("MISMATCH (PGT_HYBRID_HOST_BYTES=%d)" % cut, cmd, a.returncode, c.returncode, a.stderr[-200:], c.stderr[-200:], "files kept in", d)
+                keep_failure(d, cmd, {"single": a, "hybrid": c})
+                sys.exit(1)
+            counts["hybrid"] = counts.get("hybrid", 0) + 1
         if True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
             limit = int(rng.choice([1, 70000, 150000]))
             env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))

@@ -625,6 +625,71 @@ def test_dxy_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, orac
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_cli_hybrid_ingest_prints_the_same_tsv(hosts, tmp_path, oracle):
+    """Large inputs on one GPU: the host threads parse the head of the text beside HIP start-up, the GPU parses the tail, the
+    columns meet on the GPU (host_common.h: ingest_hybrid; by default from 1.25 GiB on, cut near 1 GiB — here moved with
+    PGT_HYBRID_HOST_BYTES).  stdout, stderr and the exit code are those of the run without it: reference-made goldens with the
+    cut at every few bytes, 3 * 10^6-line tables (fstWindow per-window / group / sliding query, hetWindow) with the cut in
+    many places, a blank line in the head, at the cut and in the tail, a bad line in the head and in the tail (global line
+    numbers), a chromosome run that continues across the cut."""
+    import synth
+
+    def hybrid(cmd, cut, **env):
+        return run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES=str(cut), **env))
+
+    for c in helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::5]:
+        f = tmp_path / "in.txt"
+        f.write_text(c["input"])
+        for cut in range(1, len(c["input"]) + 2, max(1, len(c["input"]) // 7)):
+            r = hybrid([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], cut)
+            assert r.returncode == 0, (cut, r.stderr[-300:])
+            tsv_equal(r.stdout, c["stdout"], 4)
+    rng = np.random.default_rng(2024)
+    n = 3_000_000
+    chr_ids, pos = synth.chromosomes(rng, n, 7, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    big = tmp_path / "big.fst.txt"
+    oracle.write_fst_text(str(big), chr_ids, pos, a, b)
+    size = os.path.getsize(big)
+    for W, S in ((50_000, 10_000), (50_000, 100), (700, 5)):
+        cmd = [hosts["fstWindow"], str(big), str(W), str(S)]
+        one = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES="0"))
+        assert one.returncode == 0 and one.stdout
+        for cut in (1, 4097, size // 3, size // 2 + 11, size - 40, size, size + 5):
+            r = hybrid(cmd, cut)
+            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, cut, r.stderr[-300:])
+    timed = hybrid([hosts["fstWindow"], str(big), "50000", "10000"], size // 2, PGT_HOST_TIMING="1")
+    assert "head on the host" in timed.stderr and "columns joined" in timed.stderr
+    lines = big.read_text().splitlines(True)
+    at = len("".join(lines[:1_500_000]))  # the cut will fall right behind line 1 500 000
+    odd = tmp_path / "odd.fst.txt"
+    cmd = [hosts["fstWindow"], str(odd), "50000", "10000"]
+    for where in (400_000, 1_500_000, 2_600_000):  # blank line: in the head, first line of the tail, in the tail
+        odd.write_text("".join(lines[:where]) + " \n" + "".join(lines[where:]))
+        one, r = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="0")), hybrid(cmd, at)
+        assert one.returncode == 0 and (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), where
+    for where in (400_000, 2_600_000):  # a bad line in the head / in the tail
+        odd.write_text("".join(lines[:where]) + lines[where].replace("\t", "\tx", 2) + "".join(lines[where + 1:]))
+        one, r = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="0")), hybrid(cmd, at)
+        assert one.returncode == 255 and f"line {where + 1} " in one.stderr and (r.returncode, r.stdout, r.stderr) == (255, one.stdout, one.stderr), where
+    os.unlink(odd)
+    os.unlink(big)
+    g = synth.het_column(rng, n)
+    bigh = tmp_path / "big.het.txt"
+    with open(bigh, "w") as fh:
+        for lo in range(0, n, 1_000_000):
+            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    size = os.path.getsize(bigh)
+    for W, S in ((50_000, 10_000), (200_000, 64)):
+        cmd = [hosts["hetWindow"], str(bigh), str(W), str(S)]
+        one = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES="0"))
+        for cut in (1, size // 2, size - 9):
+            r = hybrid(cmd, cut)
+            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, cut, r.stderr[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_dxy_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     """dxyWindow with PGT_MAX_RESIDENT_SITES: both MAF texts are scanned for runs and row marks, then reduced block by block
     (the text of a block's rows of both files -> device parser -> reduce -> print; base-pair windows after one extra pass over
