@@ -770,17 +770,18 @@ class DeviceOpener {
 };
 
 // ---- device-side ingest (pgt_ingest_text) ---------------------------------------------------------
-// From 512 MiB of text on, the table is parsed on the GPU (the text crosses PCIe once, the columns never
-// visit the host).  Below that the host parser wins: it runs beside HIP start-up (60-200 ms on this pool),
-// which the device path has to wait for, and small inputs keep working without a GPU.  Measured at 10^8 lines
-// (profiles/r02/cli_end_to_end_1e8.md): fstWindow, 3.2 GB: 285 ms in-process on the device path (113 HIP
-// start-up, 129 upload at 25 GB/s, 18 parse kernel) against 402 ms with the host parser; dxyWindow, 2 x 0.7 GB:
-// 179 against 171 ms.  PGT_GPU_INGEST=0 forces the host parser, =1 the device one.  With PGT_COLUMN_CACHE the
-// host path is taken (the cache holds host columns).
+// From 2 GiB of text on, the GPU parses (the tail of) the table: its text crosses PCIe once, its columns never visit the
+// host.  Below that the host parser wins or ties: it runs beside HIP start-up (70-260 ms on this pool), which the device path
+// has to wait for, it writes its columns into huge pages (round 3), and small inputs keep working without a GPU.  Measured,
+// fstWindow end to end, alternating runs, quartile of 12 (profiles/r03/hybrid_ingest_ab.txt): 1.6 GB of text 0.17 s with the
+// host parser against 0.24 with the device parser; 3.3 GB 0.37 against 0.32 (0.31 with the head on the host, ingest_hybrid
+// below); 6.7 GB 1.00 against 0.52 (0.54).  (Until round 3 the switch was at 512 MiB: the host parser's columns then lived in
+// 4-KiB pages and cost 0.2 s more at 3.3 GB.)  PGT_GPU_INGEST=0 forces the host parser, =1 the device one.  With
+// PGT_COLUMN_CACHE the host path is taken (the cache holds host columns).
 inline bool gpu_ingest_wanted(size_t text_bytes) {
     if (const char *c = std::getenv("PGT_COLUMN_CACHE"); c && *c) return false;
     if (const char *e = std::getenv("PGT_GPU_INGEST")) return std::atoi(e) != 0;
-    return text_bytes >= ((size_t)512 << 20);
+    return text_bytes >= ((size_t)2 << 30);
 }
 struct DeviceTable {
     pgt_ingest *ing = nullptr;
@@ -1034,12 +1035,14 @@ void reduce_on_devices(DeviceOpener &device, const std::vector<pgt_win> &win, ui
 
 // ---- large inputs, one GPU: the host parses the head of the text while HIP starts, the GPU the rest --------------------------
 // HIP start-up (70-260 ms) is dead time for the device parser, and what the host parser needs for 1-2 GB of text (14 GB/s
-// on this box's share of cores).  So from 1.25 GiB on the text is cut at a line start near 1 GiB: the host threads parse
+// on this box's share of cores).  So wherever the device parser is taken (2 GiB of text and more) the text is cut at a line
+// start near 1 GiB: the host threads parse
 // the head into huge-page columns beside HIP start-up and the GPU parses the tail behind room for the head's rows
 // (pgt_ingest_text_behind), into which the head's columns are then uploaded (20 B per line instead of 33 B of text): one
-// contiguous column per field, no copy.  Measured, fstWindow end to end, alternating runs (profiles/r03/hybrid_ingest_ab.txt): 1.65 GB 0.34 -> 0.17-0.25 s,
-// 3.3 GB 0.44 -> 0.30 s, 10 GB 0.69 -> 0.70 s; a head of 2-3 GiB is worse than 1 GiB (its parse then runs beside the
-// upload of the tail and slows it).  PGT_HYBRID_HOST_BYTES=<n> moves the cut (0: off).
+// contiguous column per field, no copy.  Measured, fstWindow end to end, alternating runs on two boxes
+// (profiles/r03/hybrid_ingest_ab.txt; medians): 3.3 GB 0.44 -> 0.30 s and 0.34 -> 0.32 s, 6.7 GB 0.55 -> 0.59, 10 GB 0.69 -> 0.70:
+// a gain where HIP start-up is a large part of the run, nothing beyond; a head of 2-3 GiB is worse than 1 GiB (its parse then
+// runs beside the upload of the tail and slows it).  PGT_HYBRID_HOST_BYTES=<n> moves the cut (0: off).
 //   0  not taken (small input, switched off, or the device refused the tail): nothing was changed
 //   1  `tab` and `runs` hold the table on the GPU
 //   2  the data ended at a blank line inside the head: `host_tab` (n rows) and `runs` hold it on the host
@@ -1047,7 +1050,7 @@ struct HybridColumn { int token; size_t elem; const void *host; };  // host: the
 template <class Table, class HostColumns>
 int ingest_hybrid(DeviceOpener &device, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what, const char *path,
                   Table &host_tab, HostColumns host_columns, DeviceTable &tab, Runs &runs, size_t *n_rows, PhaseTimer &timer) {
-    size_t host_bytes = (size_t)1 << 30, least = (size_t)5 << 28;  // cut near 1 GiB, inputs from 1.25 GiB on
+    size_t host_bytes = (size_t)1 << 30, least = (size_t)5 << 28;  // cut near 1 GiB, a tail of 256 MiB at least (the caller asks from 2 GiB on)
     if (const char *v = std::getenv("PGT_HYBRID_HOST_BYTES")) {
         host_bytes = (size_t)std::max<long long>(std::atoll(v), 0);
         least = host_bytes + 1;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the device parser starts to pay: fstWindow end to end (wall time of the process) with the host parser, with the
-device parser alone and with the default (from 1.25 GiB of text on the head goes to the host parser beside HIP start-up,
+device parser alone and with the default (from 2 GiB of text on the head goes to the host parser beside HIP start-up,
 the tail to the GPU), alternating, at several table sizes.  The host parser runs beside HIP start-up and uploads 20 B of columns per line; the
 device parser has to wait for HIP and uploads the ~33 B of text per line.  Markdown on stdout.
 usage: python tests/ingest_crossover.py [lines ...]"""
@@ -25,7 +25,7 @@ def main():
     exe = os.path.join(ROOT, "popgenomicstools_amd", "bin", "fstWindow")
     d = tempfile.mkdtemp(prefix="pgt_cross_")
     f = os.path.join(d, "fst.txt")
-    print("| lines | text MB | host parser: wall s | in-process ms | device parser alone: wall s | in-process ms | default (from 1.25 GiB on: head on the host, tail on the GPU): wall s | in-process ms |")
+    print("| lines | text MB | host parser: wall s | in-process ms | device parser alone: wall s | in-process ms | default (from 2 GiB on: head on the host, tail on the GPU): wall s | in-process ms |")
     print("|---|---|---|---|---|---|---|---|")
     for n in sizes:
         rng = np.random.default_rng(5)

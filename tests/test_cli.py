@@ -627,7 +627,7 @@ def test_dxy_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, orac
 @pytest.mark.timeout(900)
 def test_cli_hybrid_ingest_prints_the_same_tsv(hosts, tmp_path, oracle):
     """Large inputs on one GPU: the host threads parse the head of the text beside HIP start-up, the GPU parses the tail, the
-    columns meet on the GPU (host_common.h: ingest_hybrid; by default from 1.25 GiB on, cut near 1 GiB — here moved with
+    columns meet on the GPU (host_common.h: ingest_hybrid; by default from 2 GiB on, cut near 1 GiB — here moved with
     PGT_HYBRID_HOST_BYTES).  stdout, stderr and the exit code are those of the run without it: reference-made goldens with the
     cut at every few bytes, 3 * 10^6-line tables (fstWindow per-window / group / sliding query, hetWindow) with the cut in
     many places, a blank line in the head, at the cut and in the tail, a bad line in the head and in the tail (global line
