@@ -227,6 +227,36 @@ def test_blank_line_flag_for_callers_that_cut_a_text_into_pieces(ctx):
         ing.free()
 
 
+def test_ingest_behind_rows_of_the_caller(ctx):
+    """pgt_ingest_text_behind: the parsed rows land behind room for `rows_in_front` rows of the caller's own (uploaded with
+    pgt_dev_upload to pgt_ingest_column_base) — one contiguous column; pgt_ingest_column / _rows / _download still speak of
+    the parsed rows only.  An odd number of rows in front (the f64 rows then start 8 bytes off a 16-byte boundary)."""
+    import ctypes as C
+    import torch
+    lib = ctx._lib
+    text = b"".join(b"c%d\t%d\t0.%03d\t%d.5\n" % (i // 4, 10 * i + 1, i, i) for i in range(9))
+    toks = (C.c_uint8 * 4)(*FST)
+    for front in (0, 1, 3, 1000):
+        h = C.c_void_p(0)
+        assert lib.pgt_ingest_text_behind(ctx._ctx, text, len(text), toks, 4, front, C.byref(h)) == _lib.PGT_OK
+        assert lib.pgt_ingest_rows(h) == 9 and lib.pgt_ingest_bad_line(h) == -1
+        for token, dt, tdt, mine in ((1, np.uint32, torch.int32, np.arange(front, dtype=np.uint32) + 7),
+                                     (3, np.float64, torch.float64, np.arange(front, dtype=np.float64) * 0.25)):
+            base, col = lib.pgt_ingest_column_base(h, token), lib.pgt_ingest_column(h, token)
+            assert col - base == front * np.dtype(dt).itemsize
+            if front:
+                assert lib.pgt_dev_upload(ctx._ctx, base, mine.ctypes.data, mine.nbytes) == _lib.PGT_OK
+            whole = torch.empty(front + 9, dtype=tdt, device="cuda:0")
+            assert lib.pgt_dev_copy(ctx._ctx, whole.data_ptr(), ctx._ctx, base, whole.numel() * whole.element_size()) == _lib.PGT_OK
+            got = whole.cpu().numpy().view(dt)
+            want = np.array([10 * i + 1 for i in range(9)], dtype=dt) if token == 1 else np.array([i + 0.5 for i in range(9)], dtype=dt)
+            assert np.array_equal(got[:front], mine) and np.array_equal(got[front:], want)
+            parsed = np.zeros(9, dtype=dt)
+            assert lib.pgt_ingest_download(ctx._ctx, h, token, parsed.ctypes.data, parsed.nbytes) == _lib.PGT_OK
+            assert np.array_equal(parsed, want)
+        lib.pgt_ingest_free(h)
+
+
 def test_absurdly_long_lines_are_refused_not_walked(ctx):
     """A line of 300 KB is not one of the tools' tables: the device path refuses the input (PGT_EDOMAIN) instead
     of letting one lane walk through it; the hosts then parse it themselves."""
