@@ -31,6 +31,18 @@ every rank --sites sites (genome = N x --sites).
 batched in one launch per step over one window table, site ranges sharded over the N GPUs, the 28 x windows
 rows of every rank delivered to rank 0 and checked bit for bit against the single-GPU call.
 
+Unattended N > 1 runs (the driver's): every phase — init / columns / gather timed / verify / roofline / peer timed —
+is announced on stderr by every rank with its elapsed seconds and runs under its own deadline (PHASE_DEADLINES_S; a
+watchdog thread per rank).  A phase that overruns ends the rank with exit code 124 and a line naming the phase, so a
+wedged rank reads as "rank 3: phase 'gather timed' exceeded its deadline of 60 s", not as a driver timeout; only the
+peer-store transport (opt-in: --exchange both / peer) is DEGRADABLE: once the gather's line is secured, a peer phase
+that overruns makes rank 0 print that line with exchange_peer marked unavailable and every rank exit 0.  The collectives
+run on RCCL (backend nccl) after a probe all-reduce that is given 60 s on a helper thread; if RCCL cannot be brought up
+the ranks agree (over the gloo control group, which always exists) to stage the 4 MB of rows through the CPU instead and
+say so in config.collective_backend.  Budget of `--gpus 8` on the 10^9-site genome: < 180 s in all — imports ~20 s,
+init + probe ~15 s, columns ~5 s, gather timed ~1 s, rank 0's rebuild of the whole 20-GB genome + single-GPU scan ~15 s,
+roofline ~1 s; the deadlines (sum 480 s) stay inside the driver's 600 s.
+
 The default N=1 run also times BASELINE configs 2, 3 and 5 in their one-GPU form at 10^8 sites
 ("extra"; --headline-only skips them, e.g. under rocprofv3 --stats) and the reference CPU path on a
 bounded sample ("cpu_baseline").  Prints ONE JSON line on rank 0.
@@ -56,9 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--winsize", type=int, default=50_000)
     ap.add_argument("--stepsize", type=int, default=10_000)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--exchange", choices=["auto", "peer", "gather"], default="auto",
-                    help="how rows reach rank 0 when N > 1: auto = time the RCCL gather AND (where every rank can map the "
-                         "buffer) peer stores, report both, headline = gather unless peer was verified and faster")
+    ap.add_argument("--exchange", choices=["auto", "gather", "peer", "both"], default="auto",
+                    help="how rows reach rank 0 when N > 1: auto = gather = the asynchronous RCCL gather (the transport "
+                         "north_star names); both = time the gather AND, afterwards, peer stores into rank 0's buffer, report "
+                         "both, headline = gather unless peer was verified bitwise in this run and faster; peer = peer stores only")
     ap.add_argument("--cpu-sites", type=float, default=5e7,
                     help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -87,14 +100,113 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode  # stdout / stderr are inherited: rank 0's JSON line passes through
 
 
+# ---- phases, deadlines, stderr log (stdlib only: usable before torch is imported) -----------------------------
+# seconds; a deadline covers ONE entry of a phase.  PGT_BENCH_DEADLINE_SCALE scales them (tests use 0.1 … 0.3).
+PHASE_DEADLINES_S = {"init": 120, "columns": 90, "gather timed": 60, "peer timed": 60, "local timed": 120, "verify": 120,
+                     "roofline": 30, "extra configs": 600, "sustained": 120, "cpu baseline": 600}
+T_START = time.perf_counter()
+
+
+class Phases:
+    """`with phases("gather timed"):` — announces the phase on stderr (rank, seconds since start, seconds taken) and arms a
+    watchdog for it.  On overrun the watchdog thread (the main thread may sit in a HIP or collective call that never
+    returns) writes one line naming rank and phase and ends the process with os._exit: 124, or — when the phase was entered
+    `degradable=True` — after rank 0 has printed the line secured so far (`secure()`), 0."""
+
+    def __init__(self, rank=0, world=1, scale=None, stream=None):
+        import threading
+        self.rank, self.world = rank, world
+        self.scale = float(os.environ.get("PGT_BENCH_DEADLINE_SCALE", "1")) if scale is None else scale
+        self.stream = stream or sys.stderr
+        self.taken = {}            # phase -> seconds (summed over entries)
+        self.secured = None        # callable(reason) -> JSON text of the line as far as it is known (rank 0)
+        self._lock = threading.Lock()
+        self._armed = None         # (name, deadline instant, degradable)
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._stop = False
+        self._thread.start()
+
+    def say(self, msg):
+        print(f"[bench r{self.rank}/{self.world} +{time.perf_counter() - T_START:6.1f}s] {msg}", file=self.stream, flush=True)
+
+    def secure(self, make_line):
+        self.secured = make_line
+
+    def deadline_of(self, name):
+        return PHASE_DEADLINES_S[name] * self.scale
+
+    def _watch(self):
+        while not self._stop:
+            time.sleep(0.2)
+            with self._lock:
+                armed = self._armed
+            if armed and time.perf_counter() > armed[1]:
+                name, _, degradable = armed
+                # rank 0 fires 3 s early in a degradable phase: its line must be out before a launcher that sees
+                # another rank leave reaps the rest
+                self.say(f"phase '{name}' exceeded its deadline of {self.deadline_of(name):.0f} s"
+                         + (" — degrading to the result secured before it" if degradable else " — giving up (exit 124)"))
+                if degradable:
+                    if self.rank == 0 and self.secured is not None:
+                        print(self.secured(f"phase '{name}' exceeded its deadline of {self.deadline_of(name):.0f} s"), flush=True)
+                    os._exit(0)
+                os._exit(124)
+
+    def __call__(self, name, degradable=False):
+        return _Phase(self, name, degradable)
+
+    def close(self):
+        self._stop = True
+
+
+class _Phase:
+    def __init__(self, ph, name, degradable):
+        self.ph, self.name, self.degradable = ph, name, degradable
+
+    def __enter__(self):
+        ph = self.ph
+        slack = 3.0 if (self.degradable and ph.rank == 0) else 0.0
+        self.t0 = time.perf_counter()
+        with ph._lock:
+            ph._armed = (self.name, self.t0 + max(ph.deadline_of(self.name) - slack, 0.5), self.degradable)
+        ph.say(f"{self.name}: start (deadline {ph.deadline_of(self.name):.0f} s)")
+        fault_point(ph, self.name)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        ph = self.ph
+        with ph._lock:
+            ph._armed = None
+        dt = time.perf_counter() - self.t0
+        ph.taken[self.name] = ph.taken.get(self.name, 0.0) + dt
+        ph.say(f"{self.name}: {'FAILED (' + et.__name__ + ')' if et else 'done'} in {dt:.2f} s")
+        return False
+
+
+def fault_point(ph, name):
+    """Test hook (tests/test_bench_script.py): PGT_BENCH_FAULT="<rank>:<phase>:<die|hang>" makes that rank die (exit 17) or
+    hang at the start of that phase, as a wedged GPU or a lost peer would."""
+    spec = os.environ.get("PGT_BENCH_FAULT")
+    if not spec:
+        return
+    r, phase, what = spec.split(":")
+    if int(r) == ph.rank and phase == name:
+        ph.say(f"fault injected: {what} in phase '{name}'")
+        if what == "die":
+            os._exit(17)
+        while True:
+            time.sleep(1)
+
+
 if __name__ == "__main__":
     _args = parse_args()
     if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(_args))
 
-import numpy as np
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL, hipIpc)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -187,6 +299,38 @@ def timed_config(ctx, call, alg_bytes, reps=15):
             "roofline_frac": alg_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def sustained_leg(step, alg_bytes_per_step, sites, seconds=2.5, chunks=10):
+    """>= `seconds` of back-to-back headline steps, WALL-timed (perf_counter between two device synchronisations), so that
+    an outside sampler (rocm-smi, the driver's) sees the GPU busy and a clock droop under sustained load would show: the
+    rate of each tenth of the run is reported beside the whole (HIP events between the chunks)."""
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 10
+    per_chunk = max(1, int(np.ceil(seconds / per / chunks)))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for c in range(chunks):
+        for _ in range(per_chunk):
+            step()
+        marks[c + 1].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    steps = per_chunk * chunks
+    chunk_gbs = [alg_bytes_per_step * per_chunk / (marks[c].elapsed_time(marks[c + 1]) * 1e-3) / 1e9 for c in range(chunks)]
+    return {"config": f"{steps} back-to-back steps of the headline workload, wall-clocked between two device synchronisations",
+            "steps": steps, "wall_seconds": wall, "ms_per_step": wall / steps * 1e3, "sites_per_s": sites * steps / wall,
+            "GB_per_s": alg_bytes_per_step * steps / wall / 1e9, "frac_of_hbm_peak": alg_bytes_per_step * steps / wall / 1e9 / HBM_PEAK_GBS,
+            "chunk_GB_per_s": [round(x, 1) for x in chunk_gbs],
+            "first_vs_last_chunk": chunk_gbs[-1] / chunk_gbs[0]}
+
+
 def extra_configs(ctx, dev, W, S, tree_pool):
     """BASELINE configs 2, 3, 5 (one-GPU forms) at 10^8 sites in 20 chromosomes, same generator."""
     n8 = 100_000_000
@@ -271,6 +415,76 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     return out
 
 
+def kernel_source_sha256():
+    """SHA-256 over the sources the build kernels are compiled from (what profiles/pmc_headline.json is keyed on)."""
+    h = hashlib.sha256()
+    for f in ("pgt_kernels.hip", "pgt_device.h"):
+        with open(os.path.join(ROOT, "popgenomicstools_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(n, n_tables):
+    """-> (HBM bytes per launch of the build kernel from the committed PMC passes, or None; where the figure comes from).
+    profiles/pmc_headline.json is written by tools/collect_profiles.sh from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    the 10^9-site headline workload, together with the hash of the kernel sources it was measured on: a tree whose kernels
+    have changed since reports null instead of a stale constant."""
+    path = os.path.join(ROOT, "profiles", "pmc_headline.json")
+    if not (n == 1_000_000_000 and n_tables == 1):
+        return None, "null: the committed PMC passes cover the 10^9-site, one-pair headline workload only"
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError) as e:
+        return None, f"null: {path} unreadable ({e})"
+    if rec.get("kernel_source_sha256") != kernel_source_sha256():
+        print("bench.py: WARNING: profiles/pmc_headline.json was measured on other kernel sources (hash differs): "
+              "roofline.traffic = null; rerun tools/collect_profiles.sh", file=sys.stderr, flush=True)
+        return None, "null: profiles/pmc_headline.json was measured on other kernel sources (SHA-256 of csrc/pgt_kernels.hip + pgt_device.h differs)"
+    return float(rec["traffic_bytes_per_launch"]), (
+        f"profiles/pmc_headline.json ({rec.get('collected', '?')}): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+        f"`{rec.get('command', '?')}`, {rec.get('dispatches', '?')} dispatches each: 2 x {rec.get('fetch_kib')} KiB (gfx950: FETCH_SIZE "
+        f"reports half the bytes of a wide coalesced read, MI355X_MICROARCH.md 'HBM / rocprofv3') + {rec.get('write_kib')} KiB written; "
+        "measured on kernel sources with the same SHA-256 as this tree's, not by this run")
+
+
+def bring_up_collectives(world, rank, dev, ph):
+    """-> (group for the data-path collectives, device their tensors live on, description).
+    The default group is gloo over 127.0.0.1 (the control plane: agreement and verdict flags; it comes up wherever TCP does).
+    RCCL (backend nccl) is a second group, probed with one all-reduce on a helper thread that gets 60 s: if the probe
+    fails or does not return on ANY rank, all ranks agree over gloo to stage the rows through the CPU instead."""
+    import threading
+    from datetime import timedelta
+    dist.init_process_group("gloo", timeout=timedelta(seconds=max(30.0, ph.deadline_of("init"))))
+    want = os.environ.get("PGT_BENCH_BACKEND", "nccl")  # rehearsal knob: gloo = skip RCCL altogether
+    if want != "nccl":
+        return None, torch.device("cpu"), f"{want} (REHEARSAL: PGT_BENCH_BACKEND)"
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")  # an abandoned probe must not abort the process later
+    box = {}
+
+    def probe():
+        try:
+            g = dist.new_group(backend="nccl", timeout=timedelta(minutes=30), device_id=dev)  # nccl == RCCL on ROCm
+            t = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(t, group=g)
+            box["sum"] = float(t.item())
+            box["group"] = g
+        except Exception as e:  # noqa: BLE001 — any failure means "no RCCL", the reason is reported
+            box["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    th.join(min(60.0, 0.5 * ph.deadline_of("init")))
+    ok = 1 if (box.get("sum") == float(world)) else 0
+    why = box.get("error") or ("probe all-reduce did not return in time" if th.is_alive() else f"probe all-reduce gave {box.get('sum')}")
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo
+    if int(flag.item()) == 1:
+        return box["group"], dev, "nccl (RCCL)"
+    ph.say("RCCL unusable on some rank" + (f" (here: {why})" if not ok else "") + " — rows will be staged through the CPU over gloo")
+    return None, torch.device("cpu"), "gloo, rows staged through the CPU (FALLBACK: RCCL could not be brought up" + (f": {why}" if not ok else " on another rank") + ")"
+
+
 def main():
     args = parse_args()
     pairs_mode = args.workload == "pairs"
@@ -281,58 +495,61 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # Rehearsal knobs for a one-GPU box (never set by the driver): PGT_BENCH_BACKEND=gloo moves the
-    # collectives to CPU staging, PGT_BENCH_SHARE_GPU=1 puts every rank on GPU 0.  The measured
-    # configuration is always the default: one GPU per rank, backend nccl (= RCCL over xGMI).
-    backend = os.environ.get("PGT_BENCH_BACKEND", "nccl")
+    ph = Phases(rank, world)
+    ph.say(f"imports done; pid {os.getpid()}")
+    # Rehearsal knobs for a one-GPU box (never set by the driver): PGT_BENCH_BACKEND=gloo skips RCCL (rows staged through
+    # the CPU), PGT_BENCH_SHARE_GPU=1 puts every rank on GPU 0.  The measured configuration is always the default: one
+    # GPU per rank, collectives on RCCL over xGMI.
     dev_index = 0 if os.environ.get("PGT_BENCH_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    group, coll_dev, backend_desc = None, dev, "none (single GPU)"
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
+        with ph("init"):
+            group, coll_dev, backend_desc = bring_up_collectives(world, rank, dev, ph)
+        ph.say("collectives: " + backend_desc)
 
     W, S = args.winsize, args.stepsize
     mult = world if args.scaling == "weak" else 1
     n_total = int(args.sites) * mult
-    genome = SynthGenome(SEED, n_total, args.chroms * mult)
-    win = pgt.build_windows_sites(genome.run_len, W, S)  # host, O(#windows), identical on every rank
-    shards = pgt.plan_shards(win, world)
-    sh = shards[rank]
-    site_lo, site_hi = int(sh["site_lo"]), int(sh["site_hi"])
-    local = np.array(win[int(sh["win_begin"]): int(sh["win_end"])], dtype=WIN_DTYPE, copy=True)
-    local["lo"] -= site_lo
-    local["hi"] -= site_lo
-    n = site_hi - site_lo  # sites resident on this GPU (own block + halo)
+    with ph("columns"):
+        genome = SynthGenome(SEED, n_total, args.chroms * mult)
+        win = pgt.build_windows_sites(genome.run_len, W, S)  # host, O(#windows), identical on every rank
+        shards = pgt.plan_shards(win, world)
+        sh = shards[rank]
+        site_lo, site_hi = int(sh["site_lo"]), int(sh["site_hi"])
+        local = np.array(win[int(sh["win_begin"]): int(sh["win_end"])], dtype=WIN_DTYPE, copy=True)
+        local["lo"] -= site_lo
+        local["hi"] -= site_lo
+        n = site_hi - site_lo  # sites resident on this GPU (own block + halo)
 
-    def load_columns(lo_, hi_):
-        """-> (pos, [a per pair], [b per pair]) of sites [lo_, hi_) on this GPU"""
-        if not pairs_mode:
-            p_, a_, b_ = genome.fst_columns_t(lo_, hi_, dev)
-            return p_, [a_], [b_]
-        cols = [genome.pair_columns_t(k, lo_, hi_, dev) for k in range(n_tables)]
-        return genome.pos_t(lo_, hi_, dev), [c[0] for c in cols], [c[1] for c in cols]
+        def load_columns(lo_, hi_):
+            """-> (pos, [a per pair], [b per pair]) of sites [lo_, hi_) on this GPU"""
+            if not pairs_mode:
+                p_, a_, b_ = genome.fst_columns_t(lo_, hi_, dev)
+                return p_, [a_], [b_]
+            cols = [genome.pair_columns_t(k, lo_, hi_, dev) for k in range(n_tables)]
+            return genome.pos_t(lo_, hi_, dev), [c[0] for c in cols], [c[1] for c in cols]
+
+        mycols = load_columns(site_lo, site_hi)
+        pos, a, b = mycols[0], mycols[1][0], mycols[2][0]
+        win_d = windows_to_device(local, dev)
+        ctx = pgt.Context(dev_index)
+        ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
+        want_extra = world == 1 and not args.headline_only and not pairs_mode
+        tree_bytes = max(ctx.tree_bytes(PGT_STAT_FST, n), 28 * ctx.tree_bytes(PGT_STAT_FST, 100_000_000),
+                         ctx.tree_bytes(PGT_STAT_DXY, 100_000_000) + 2 * ctx.tree_bytes(PGT_STAT_HET, 100_000_000)) \
+            if want_extra else n_tables * ctx.tree_bytes(PGT_STAT_FST, n)
+        tree = torch.empty(tree_bytes, dtype=torch.uint8, device=dev)
+        counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64) * n_tables  # rows per rank and step
+        ctx.set_window_step(S)  # the query strategy follows (W, S) of the whole table, not a rank's slice of it
+        torch.cuda.synchronize()
+    ph.say(f"{n} sites resident ({n * 20 * n_tables / 1e9:.2f} GB of columns), {int(counts[rank])} rows per step")
 
     def scan(cols, wtab, out, tree_):
         if pairs_mode:
             return ctx.fst_reduce_pairs_dev(cols[0], cols[1], cols[2], wtab, out=out, tree=tree_)
         return ctx.fst_reduce_dev(cols[0], cols[1][0], cols[2][0], wtab, out=out, tree=tree_)
-
-    mycols = load_columns(site_lo, site_hi)
-    pos, a, b = mycols[0], mycols[1][0], mycols[2][0]
-    win_d = windows_to_device(local, dev)
-    ctx = pgt.Context(dev_index)
-    ctx.set_max_window(int((win["hi"] - win["lo"]).max()))  # = W: tree levels above 8192 sites are not needed
-    want_extra = world == 1 and not args.headline_only and not pairs_mode
-    tree_bytes = max(ctx.tree_bytes(PGT_STAT_FST, n), 28 * ctx.tree_bytes(PGT_STAT_FST, 100_000_000),
-                     ctx.tree_bytes(PGT_STAT_DXY, 100_000_000) + 2 * ctx.tree_bytes(PGT_STAT_HET, 100_000_000)) \
-        if want_extra else n_tables * ctx.tree_bytes(PGT_STAT_FST, n)
-    tree = torch.empty(tree_bytes, dtype=torch.uint8, device=dev)
-    counts = (shards["win_end"] - shards["win_begin"]).astype(np.int64) * n_tables  # rows per rank and step
-    ctx.set_window_step(S)  # the query strategy follows (W, S) of the whole table, not a rank's slice of it
 
     def timed_region(ex):
         def step():
@@ -343,7 +560,7 @@ def main():
         def fence():
             ex.flush()
             if world > 1:
-                dist.barrier()
+                dist.barrier(group=group)
             torch.cuda.synchronize()
 
         for _ in range(args.warmup):
@@ -356,7 +573,7 @@ def main():
         dt_ = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt_], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             dt_ = float(t.item())
         return dt_
 
@@ -377,102 +594,77 @@ def main():
 
     can_verify = world > 1 and not args.no_verify and (args.scaling == "strong" or n_total <= 2_000_000_000)
 
-    def run_transport(mode):
+    def run_transport(mode, degradable=False):
         """One row transport: timed region + the table of its last step + the bitwise check.  Collective."""
-        try:
-            ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=mode, coll_device=coll_dev, tables=n_tables)
-        except PgtError as e:  # peer: the buffer cannot be mapped by every rank (decided collectively)
-            return {"mode": mode, "available": False, "why": str(e)}
-        dt_ = timed_region(ex)
-        table_ = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
+        with ph(f"{mode} timed", degradable=degradable):
+            try:
+                ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, mode=mode, coll_device=coll_dev, tables=n_tables,
+                                 group=group)
+            except PgtError as e:  # peer: the buffer cannot be mapped by every rank (decided collectively)
+                return {"mode": mode, "available": False, "why": str(e)}
+            dt_ = timed_region(ex)
+            table_ = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
         res = {"mode": ex.mode, "available": True, "dt": dt_, "table": table_, "verified": None}
         if world > 1:
-            verdict = torch.zeros(1, dtype=torch.int32, device=coll_dev)
-            if rank == 0 and can_verify:
-                verdict[0] = 0 if single_gpu_table() == table_.tobytes() else 1
-            dist.broadcast(verdict, src=0)
-            res["verified"] = (int(verdict.item()) == 0) if can_verify else None
-        ex.close()
+            with ph("verify", degradable=degradable):
+                verdict = torch.zeros(1, dtype=torch.int32)
+                if rank == 0 and can_verify:
+                    verdict[0] = 0 if single_gpu_table() == table_.tobytes() else 1
+                dist.broadcast(verdict, src=0)  # gloo control group
+                res["verified"] = (int(verdict.item()) == 0) if can_verify else None
+                ex.close()
+        else:
+            ex.close()
         return res
 
-    if world == 1:
-        runs = [run_transport("local")]
-    else:
-        runs = [run_transport(m) for m in (("gather", "peer") if args.exchange == "auto" else (args.exchange,))]
-    usable = [r for r in runs if r["available"]]
-    if not usable:
-        raise SystemExit("bench.py: --exchange peer, but the row buffer cannot be mapped by every rank: " + runs[0]["why"])
-    bad = [r["mode"] for r in usable if r["verified"] is False]
-    if bad and rank == 0:
-        print(f"bench.py: the table assembled by {bad} differs from the single-GPU table of the same genome", file=sys.stderr, flush=True)
-    # headline: the gather, unless peer stores were verified in this run and were faster; an unverifiable run
-    # (--no-verify, genome too large to rebuild) never promotes peer stores
-    good = [r for r in usable if r["verified"] is not False]
-    if not good:
-        raise SystemExit("bench.py: no row transport delivered the single-GPU table")
-    head = good[0]
-    for r in good[1:]:
-        if r["mode"] == "peer" and r["verified"] and r["dt"] < head["dt"]:
-            head = r
-    dt, table, head_mode = head["dt"], head["table"], head["mode"]
-    rows_check, sha, rows = None, None, None
-    if world > 1 and rank == 0:
-        rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
-                      ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
-    if rank == 0:
+    def roofline_events():
+        """HIP events on the launch stream, around the build pass only -> (avg build ms, avg query ms)"""
+        with ph("roofline"):
+            scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
+            ctx.set_profiling(True)
+            build_ms, query_ms = [], []
+            for _ in range(max(5, min(args.steps, 20))):
+                scan(mycols, win_d, scratch, tree)
+                bm, qm = ctx.last_kernel_ms()
+                build_ms.append(bm)
+                query_ms.append(qm)
+            ctx.set_profiling(False)
+        return float(np.mean(build_ms)), float(np.mean(query_ms))
+
+    def assemble(runs, build_avg, query_avg, extra, cpu, note=None):
+        """rank 0: the JSON line from the transports that have run so far."""
+        usable = [r for r in runs if r["available"]]
+        good = [r for r in usable if r["verified"] is not False]
+        # headline: the gather, unless peer stores were verified in this run and were faster; an unverifiable run
+        # (--no-verify, genome too large to rebuild) never promotes peer stores
+        head = good[0]
+        for r in good[1:]:
+            if r["mode"] == "peer" and r["verified"] and r["dt"] < head["dt"]:
+                head = r
+        dt, table, head_mode = head["dt"], head["table"], head["mode"]
+        rows_check = None
+        if world > 1:
+            rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
+                          ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
         sha = hashlib.sha256(table.tobytes()).hexdigest()
         rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)
         assert rows.size == n_tables * win.size  # table-major: pair 0's rows come first
-    exchange_report = {}
-    for r in runs:
-        key = "exchange_" + r["mode"]
-        if not r["available"]:
-            exchange_report[key] = {"available": False, "why": r["why"]}
-        else:
-            exchange_report[key] = {"ms_per_step": r["dt"] / args.steps * 1e3, "sites_per_s": float(n_total) * args.steps / r["dt"],
-                                    "rows_check": ("bitwise equal" if r["verified"] else "DIFFERS") if r["verified"] is not None else "not verified",
-                                    "headline": r is head}
-    if bad and args.exchange != "auto":
-        raise SystemExit("bench.py: the multi-GPU table differs from the single-GPU table of the same genome")
-
-    # --- roofline of the dominant kernel: HIP events on the launch stream, around the build pass only
-    scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
-    ctx.set_profiling(True)
-    build_ms, query_ms = [], []
-    for _ in range(max(5, min(args.steps, 20))):
-        scan(mycols, win_d, scratch, tree)
-        bm, qm = ctx.last_kernel_ms()
-        build_ms.append(bm)
-        query_ms.append(qm)
-    ctx.set_profiling(False)
-    build_avg = float(np.mean(build_ms))
-    achieved = BYTES_PER_SITE * n_tables * n / (build_avg * 1e-3) / 1e9  # GB/s
-    # HBM traffic of one build launch from the PMC passes committed under profiles/r03 (the same kernel on the same
-    # 10^9-site, one-pair workload): 1.008 x the algorithmic bytes — every column byte is fetched once
-    traffic = (2 * 7812576.5 + 124003.5) * 1024.0 if (n == 1_000_000_000 and n_tables == 1) else None
-
-    # --- sanity: a sample of windows against float64 sums taken by torch (independent path)
-    if rank == 0:
-        mine = np.arange(int(sh["win_begin"]), int(sh["win_end"]))
-        for i in mine[np.linspace(0, mine.size - 1, 7).astype(int)]:
-            lo, hi = int(win["lo"][i]) - site_lo, int(win["hi"][i]) - site_lo
-            ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())  # pair 0 = the first table
-            assert abs(rows["fst"][i] - ref) <= 1e-9 * abs(ref) + 1e-12, (i, rows["fst"][i], ref)
-            assert rows["n"][i] == hi - lo and rows["start"][i] == (int(pos[lo]) & 0xFFFFFFFF)
-
-    extra, cpu = {}, None
-    if world > 1:
-        extra.update(exchange_report)
-    if rank == 0 and world == 1 and not pairs_mode:
-        if not args.headline_only:
-            extra = extra_configs(ctx, dev, W, S, tree)
-            ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
-            ctx.set_window_step(S)
-        if not args.no_cpu:
-            cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra)
-
-    if rank == 0:
-        per_gpu = [int(s["site_hi"] - s["site_lo"]) for s in shards]
+        extra = dict(extra)
+        for r in runs:
+            key = "exchange_" + r["mode"]
+            if not r["available"]:
+                extra[key] = {"available": False, "why": r["why"]}
+            elif world > 1:
+                extra[key] = {"ms_per_step": r["dt"] / args.steps * 1e3, "sites_per_s": float(n_total) * args.steps / r["dt"],
+                              "rows_check": ("bitwise equal" if r["verified"] else "DIFFERS") if r["verified"] is not None else "not verified",
+                              "headline": r is head}
+        if note:
+            extra["note"] = note
+        extra["phase_seconds"] = {k: round(v, 3) for k, v in ph.taken.items()}
+        extra["seconds_since_start"] = round(time.perf_counter() - T_START, 2)
+        achieved = BYTES_PER_SITE * n_tables * n / (build_avg * 1e-3) / 1e9  # GB/s
+        traffic, traffic_source = pmc_traffic(n, n_tables)
+        per_gpu = [int(s_["site_hi"] - s_["site_lo"]) for s_ in shards]
         line = {
             "metric": ("genomic sites/sec for 2-pop FST window scan" if not pairs_mode else
                        f"genomic sites/sec for the all-pairs FST window scan ({n_tables} population pairs per site)"),
@@ -487,12 +679,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            # every transport that ran delivered the single-GPU table (or was not verifiable by request)
+            "ok": all(r["verified"] is not False for r in usable),
             "config": {"workload": (f"fstWindow 2 pops x {n_total:.0e} sites total" if not pairs_mode else
                                     f"fstWindow all {n_tables} pairs of 8 populations x {n_total:.0e} sites total, one batched call per step,")
                                    + f" in {genome.run_len.size} chromosomes"
                                    + (f" sharded x{world} by window blocks (pgt_plan_shards)" if world > 1 else "")
                                    + f", window {W} sites / step {S} sites, {win.size} windows, columns resident in HBM"
-                                   + (f", rows to rank 0 by {'peer stores over xGMI' if head_mode == 'peer' else 'async RCCL gather'}"
+                                   + (f", rows to rank 0 by {'peer stores over xGMI' if head_mode == 'peer' else 'async gather'}"
                                       if world > 1 else ""),
                        "baseline_config": ("BASELINE configs[3] (10^9-site fstWindow scan sharded over the GPUs; at N=1 the same genome "
                                            "on one GPU: the size north_star's roofline target is quoted on); configs[1], [2], [4] in `extra`"
@@ -500,28 +694,85 @@ def main():
                                            "BASELINE configs[4]: fstWindow all-pairs of 8 populations x 10^8 sites, pairs batched in one launch, "
                                            "site ranges sharded over the GPUs"),
                        "sites_total": n_total, "sites_resident_per_gpu": per_gpu, "winsize": W, "stepsize": S,
-                       "windows": int(win.size), "seed": SEED, "row_exchange": head_mode,
-                       "parallelism": (f"site-range shards x{world}" + ("" if backend == "nccl" else f" (REHEARSAL: backend {backend})"))
-                                      if world > 1 else "single GPU"},
+                       "windows": int(win.size), "seed": SEED, "row_exchange": head_mode, "collective_backend": backend_desc,
+                       "parallelism": f"site-range shards x{world}" if world > 1 else "single GPU"},
             "rows_sha256": sha,
             "rows_check": rows_check,
             "roofline": {"bound": "hbm", "kernel": "fst_build_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch of the build kernel (read + written)",
-                         "traffic_source": "profiles/r03/pmc_counters.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                                           "`bench.py --steps 3 --warmup 1 --no-cpu --headline-only` (tools/collect_profiles.sh), 9 dispatches each: "
-                                           "2 x 7812576.5 KiB (gfx950: FETCH_SIZE counts half of a wide coalesced read) + 124003.5 KiB written; a "
-                                           "constant of the committed profile, not measured by this run (null for any other workload)",
-                         "kernel_ms": build_avg, "query_kernel_ms": float(np.mean(query_ms)),
+                         "traffic_source": traffic_source,
+                         "kernel_ms": build_avg, "query_kernel_ms": query_avg,
                          "algorithmic_bytes_per_launch": BYTES_PER_SITE * n_tables * n, "sites_per_launch": n},
             "cpu_baseline": cpu,
             "extra": extra,
         }
-        print(json.dumps(line), flush=True)
+        return json.dumps(line)
+
+    def sanity(table):
+        """rank 0: a sample of its windows against float64 sums taken by torch (an independent path)."""
+        rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)
+        mine = np.arange(int(sh["win_begin"]), int(sh["win_end"]))
+        for i in mine[np.linspace(0, mine.size - 1, 7).astype(int)]:
+            lo, hi = int(win["lo"][i]) - site_lo, int(win["hi"][i]) - site_lo
+            ref = float(a[lo:hi].sum()) / float(b[lo:hi].sum())  # pair 0 = the first table
+            assert abs(rows["fst"][i] - ref) <= 1e-9 * abs(ref) + 1e-12, (i, rows["fst"][i], ref)
+            assert rows["n"][i] == hi - lo and rows["start"][i] == (int(pos[lo]) & 0xFFFFFFFF)
+
+    if world == 1:
+        modes = ["local"]
+    else:
+        modes = {"auto": ["gather"], "gather": ["gather"], "peer": ["peer"], "both": ["gather", "peer"]}[args.exchange]
+    runs = [run_transport(modes[0])]
+    if not runs[0]["available"]:
+        raise SystemExit("bench.py: --exchange peer, but the row buffer cannot be mapped by every rank: " + runs[0]["why"])
+    if runs[0]["verified"] is False:
+        if rank == 0:
+            print(f"bench.py: the table assembled by '{runs[0]['mode']}' differs from the single-GPU table of the same genome",
+                  file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    if rank == 0:
+        sanity(runs[0]["table"])
+    build_avg, query_avg = roofline_events()
+    if len(modes) > 1:
+        # the gather's line is secured: whatever the opt-in second transport does (a mapping that never returns, stores
+        # that never land) can no longer cost the run its result
+        if rank == 0:
+            ph.secure(lambda why: assemble(runs + [{"mode": modes[1], "available": False, "why": why}], build_avg, query_avg, {}, None,
+                                           note="second transport abandoned: " + why))
+        runs.append(run_transport(modes[1], degradable=True))
+        if runs[1]["available"] and runs[1]["verified"] is False and rank == 0:
+            print(f"bench.py: the table assembled by '{runs[1]['mode']}' DIFFERS from the single-GPU table of the same genome "
+                  "(\"ok\": false in the line)", file=sys.stderr, flush=True)
+
+    extra, cpu = {}, None
+    if rank == 0 and world == 1 and not pairs_mode:
+        if not args.headline_only:
+            with ph("extra configs"):
+                extra = extra_configs(ctx, dev, W, S, tree)
+                ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
+                ctx.set_window_step(S)
+            with ph("sustained"):
+                sust_out = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
+                extra["sustained"] = sustained_leg(lambda: scan(mycols, win_d, sust_out, tree), BYTES_PER_SITE * n, n)
+                del sust_out
+        if not args.no_cpu:
+            with ph("cpu baseline"):
+                cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra)
+
+    if rank == 0:
+        print(assemble(runs, build_avg, query_avg, extra, cpu), flush=True)
+    ph.say("line printed" if rank == 0 else "done")
+    all_ok = all(r["verified"] is not False for r in runs if r["available"])
     ctx.close()
+    ph.close()
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        # os._exit: no destructor of an abandoned RCCL probe (or of a half-built communicator) gets to hang the exit;
+        # 3 = an explicitly requested transport delivered a table that differs ("ok": false in the line above)
+        os._exit(0 if all_ok else 3)
 
 
 if __name__ == "__main__":

@@ -243,16 +243,17 @@ static void reduce_dxy_on_devices(DeviceOpener &device, const std::vector<pgt_wi
 
 // ---- two MAF files larger than the GPU: in passes (PGT_MAX_RESIDENT_SITES, or decided from the free memory) ----------------
 // As for fstWindow (host_common.h: reduce_in_passes), with the blocks of the several-GPU path above run one after the other
-// on the first GPU: a first scan of both texts for runs and row marks; the passes need both files to list the SAME sites (run
-// for run here; position for position checked block by block on what the device parsed — files whose site lists differ go
-// through the host merge, which holds everything: -> false, the resident path runs).  Base-pair windows need every position
+// on the first GPU: a first scan of both texts for runs, row marks and a digest of the position column per 65536 rows; the
+// passes need both files to list the SAME sites (run for run and position for position — both known from that scan, before
+// anything is printed; files whose site lists differ go through the host merge, which holds everything: -> false, the
+// resident path runs).  Base-pair windows need every position
 // before the first window is known: one extra pass over file 1 that keeps only its position column (4 B per site on the
 // host).  Then per block: the text of its rows of both files -> device parser -> reduce -> its rows printed; the genome-wide
 // line from the blocks' 65536-site rows, in order, as on several GPUs.
 static bool dxy_in_passes(DeviceOpener &device, const Text &t1, const Text &t2, const char *path1, const char *path2, uint32_t W, uint32_t S,
                           int minind, int fixedsite, int skip_missing, const std::map<std::string, uint32_t> &chrsize,
                           uint64_t max_resident, PhaseTimer &timer) {
-    struct File { const char *b, *e, *end; Runs runs; std::vector<const char *> mark; size_t n; const char *path; } f[2];
+    struct File { const char *b, *e, *end; Runs runs; std::vector<const char *> mark; std::vector<uint64_t> pos_digest; size_t n; const char *path; } f[2];
     const Text *texts[2] = {&t1, &t2};
     const char *paths[2] = {path1, path2};
     for (int i = 0; i < 2; ++i) {
@@ -261,12 +262,16 @@ static bool dxy_in_passes(DeviceOpener &device, const Text &t1, const Text &t2, 
         f[i].b = hdr.p;
         f[i].e = texts[i]->end();
         f[i].path = paths[i];
-        f[i].n = scan_runs_and_marks(f[i].b, f[i].e, f[i].runs, f[i].mark, &f[i].end);
+        f[i].n = scan_runs_and_marks(f[i].b, f[i].e, f[i].runs, f[i].mark, &f[i].end, &f[i].pos_digest);
     }
     timer.lap("scan runs");
     // anything but two files with the same runs goes through the resident path — it parses both files completely before it
     // looks at their chromosomes, so a bad line is reported before "Chromosomes in MAF files differ", as the fuzzer insists
     if (f[0].n == 0 || f[1].n == 0 || f[0].n != f[1].n || f[0].runs.name != f[1].runs.name || f[0].runs.len != f[1].runs.len) return false;
+    // ... and so does a pair with the same runs but other POSITIONS (the reference's sync loop, dxyWindow.cpp:315-331, and the
+    // resident host merge accept such input): decided here, from the scan's per-block digests of the position column, before
+    // a single row is on stdout — not block by block in the middle of the run
+    if (f[0].pos_digest != f[1].pos_digest) return false;
     const uint64_t n = f[0].n;
     const Runs &runs = f[0].runs;
     pgt_ctx *ctx = device.get();
@@ -339,9 +344,8 @@ static bool dxy_in_passes(DeviceOpener &device, const Text &t1, const Text &t2, 
                     q[i] = buf[i]->data();
                 } else q[i] = pcs[i]->m.pos.data();
             }
-            if (std::memcmp(q[0], q[1], a.rows * sizeof(uint32_t)) != 0)
-                die("dxyWindow: the MAF files list different sites; reducing a table in passes (PGT_MAX_RESIDENT_SITES, or inputs larger "
-                    "than the GPU's memory) needs identical site lists");
+            if (std::memcmp(q[0], q[1], a.rows * sizeof(uint32_t)) != 0)  // cannot happen after the digest comparison above
+                die("dxyWindow: internal error: the position digests of the two MAF files agree but a block's parsed positions differ");
             if (a.m.on_device && b.m.on_device) {
                 check(pgt_dxy_reduce_cols(ctx, a.m.dev.col<uint32_t>(1), a.m.dev.col<double>(5), b.m.dev.col<double>(5), a.m.dev.col<int32_t>(6),
                                           b.m.dev.col<int32_t>(6), a.rows, minind, w, nw, o, nw * sizeof(*o), nullptr), ctx);

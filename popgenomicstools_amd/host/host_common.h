@@ -1116,8 +1116,21 @@ int ingest_hybrid(DeviceOpener &device, const char *b, const char *e, const uint
 // listed GPUs (every GPU uploads over its own PCIe link) and are printed in order.
 constexpr uint64_t kMarkEvery = 65536;  // rows between two byte marks = the smallest shard alignment of pgt_plan_shards
 
-// runs of chromosome names, the number of rows and the row marks of [b,e); stops at the first blank line like the parsers
-inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std::vector<const char *> &mark, const char **data_end) {
+// splitmix64's finaliser: the per-row mixer of the position digests below
+inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// runs of chromosome names, the number of rows and the row marks of [b,e); stops at the first blank line like the parsers.
+// pos_digest (optional): one 64-bit digest of the SECOND token (the position) per block of 65536 rows — the sum over the
+// block's rows of mix64(value of a plain digit string, or a hash of the token's bytes otherwise; + the row's index), so two
+// files list the same positions in the same rows exactly when their digests agree (up to 2^-64): how dxyWindow's passes
+// learn BEFORE the first row is printed whether the two MAF files list the same sites, without holding a position column.
+inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std::vector<const char *> &mark, const char **data_end,
+                                  std::vector<uint64_t> *pos_digest = nullptr) {
     int T = host_threads();
     if ((size_t)(e - b) < (1u << 20)) T = 1;
     const std::vector<const char *> cut = cut_at_lines(b, e, (size_t)T);
@@ -1135,12 +1148,13 @@ inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std:
     });
     for (int t = 0; t < T; ++t) off[t + 1] = off[t] + lines[t];
     mark.assign(off[T] / kMarkEvery + 2, nullptr);
-    struct Result { size_t rows = 0; bool stopped = false; const char *end = nullptr; Runs runs; };
+    struct Result { size_t rows = 0; bool stopped = false; const char *end = nullptr; Runs runs; std::vector<uint64_t> digest; };
     std::vector<Result> res(T);
     run_all([&](int t) {
         Result &r = res[t];
         Cursor c{cut[t], cut[t + 1]};
         size_t row = off[t];
+        const size_t block0 = row / kMarkEvery;  // r.digest[k]: this piece's share of block block0 + k
         while (c.p < c.end) {
             const char *line = c.p;
             c.skip_blank();
@@ -1148,6 +1162,21 @@ inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std:
             if (row % kMarkEvery == 0) mark[row / kMarkEvery] = line;
             const Tok chr = c.token();
             r.runs.add(chr.first, chr.second);
+            if (pos_digest) {
+                c.skip_blank();
+                uint64_t v = 0;
+                bool digits = !c.at_eol();
+                const char *q = c.p;
+                if (q < c.end && *q == '+') ++q;  // as to_u32
+                for (; q < c.end && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r'; ++q) {
+                    if (*q < '0' || *q > '9' || q - c.p > 18) digits = false;
+                    v = digits ? v * 10 + (uint64_t)(*q - '0') : mix64(v ^ (uint64_t)(unsigned char)*q);
+                }
+                if (!digits) v = mix64(v ^ 0xD1B54A32D192ED03ull);  // not a position: some digest that no digit string has by construction
+                const size_t k = row / kMarkEvery - block0;
+                if (k >= r.digest.size()) r.digest.resize(k + 1, 0);
+                r.digest[k] += mix64(v + 0x9E3779B97F4A7C15ull * (uint64_t)(row % kMarkEvery));
+            }
             ++row;
             c.next_line();
         }
@@ -1156,12 +1185,16 @@ inline size_t scan_runs_and_marks(const char *b, const char *e, Runs &runs, std:
     });
     size_t n = 0;
     *data_end = b;
+    if (pos_digest) pos_digest->assign(off[T] / kMarkEvery + 1, 0);
     for (int t = 0; t < T; ++t) {
         runs.append(res[t].runs);
         n = off[t] + res[t].rows;
         *data_end = res[t].end;
+        if (pos_digest)
+            for (size_t k = 0; k < res[t].digest.size(); ++k) (*pos_digest)[off[t] / kMarkEvery + k] += res[t].digest[k];
         if (res[t].stopped) break;
     }
+    if (pos_digest) pos_digest->resize((n + kMarkEvery - 1) / kMarkEvery);
     mark.resize(n / kMarkEvery + 2);
     mark[(n + kMarkEvery - 1) / kMarkEvery] = *data_end;  // the mark behind the last row
     return n;

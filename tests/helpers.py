@@ -148,3 +148,31 @@ def small_step_cases():
             chr_ids, pos, a, b, g, fst, het = make_golden.small_step_input(*key)
             seen[key] = {"chr_ids": chr_ids, "pos": pos, "a": a, "b": b, "g": g, "fst": fst, "het": het}
         yield c, seen[key]
+
+
+def write_hand_walked_case(case, header, tmp_path):
+    """Materialise one case of tests/golden/dxy_hand_walked.json -> (maf1 path, maf2 path, size file path or None)."""
+    d = tmp_path / case["name"]
+    d.mkdir(exist_ok=True)
+    paths = []
+    for key in ("pop1", "pop2"):
+        p = d / (key + ".mafs")
+        with open(p, "w") as f:
+            f.write(header + "\n")
+            for c, pos, fr, n in case[key]:
+                f.write(f"{c}\t{pos}\tA\tC\tA\t{fr:.6f}\t{n}\n")
+        paths.append(str(p))
+    sz = None
+    if case["sizes"]:
+        sz = d / "sizes.txt"
+        sz.write_text("".join(f"{c}\t{n}\n" for c, n in case["sizes"]))
+        sz = str(sz)
+    return paths[0], paths[1], sz
+
+
+def hand_walked_product_expectation(case, run):
+    """What the GPU host / C-ABI must give for a run of a hand-walked case: the reference's output, or — for the
+    documented deliberate divergences — the output of the machine on the sites both files list."""
+    if case["product"] == "same":
+        return run["stdout"], run["stderr"]
+    return case["product"]["stdout"], case["product"]["stderr"]

@@ -10,7 +10,7 @@
 //      plain member (both through gzread) give the text back; a damaged block or a truncated file is refused;
 //   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
 //      per piece and stitched with Runs::add are the runs of the whole text;
-//   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks;
+//   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks, the position digests;
 //   7. HostBuf (huge-page mappings for columns, rows and inflated text): alignment, size, every byte writable;
 //   8. resident_limit_for: which inputs are reduced in passes, and of how many sites.
 #include <dirent.h>
@@ -379,7 +379,35 @@ int main(int argc, char **argv) {
             CHECK(mark.size() >= (n + kMarkEvery - 1) / kMarkEvery + 1);
             for (size_t k = 0; k * kMarkEvery < n; ++k) CHECK(mark[k] == b + line_start[k * kMarkEvery]);
             CHECK(mark[(n + kMarkEvery - 1) / kMarkEvery] == data_end);
+            // the position digests (how dxyWindow's passes compare two files' site lists before printing anything): one per
+            // 65536 rows; independent of the thread count; blind to everything but the position column ("+7" and "7" agree);
+            // any position changed, two positions swapped or a row's position missing changes its block's digest and no other
+            std::vector<uint64_t> dig, dig1, dig2;
+            Runs r2;
+            std::vector<const char *> m2;
+            CHECK(scan_runs_and_marks(b, e, r2, m2, &data_end, &dig) == n);
+            CHECK(dig.size() == (n + kMarkEvery - 1) / kMarkEvery);
+            setenv("PGT_HOST_THREADS", "1", 1);
+            r2 = Runs{};
+            CHECK(scan_runs_and_marks(b, e, r2, m2, &data_end, &dig1) == n && dig1 == dig);
+            setenv("PGT_HOST_THREADS", "7", 1);
+            if (n > 70000) {
+                std::string other = text;  // same rows, other columns behind the position, a '+' before one position
+                for (size_t i = 0; i + 1 < other.size(); ++i)
+                    if (other[i] == '\t' && other[i + 1] == '0' && other[i + 2] == '.') other[i + 3] = '7';
+                const size_t at = line_start[66000] + (size_t)(std::strchr(b + line_start[66000], '\t') - (b + line_start[66000])) + 1;
+                other.insert(at, "+");
+                r2 = Runs{};
+                CHECK(scan_runs_and_marks(other.data(), other.data() + other.size(), r2, m2, &data_end, &dig2) == n && dig2 == dig);
+                std::string moved = text;   // one position differs, in block 1
+                moved[at] = moved[at] == '9' ? '8' : '9';
+                r2 = Runs{};
+                CHECK(scan_runs_and_marks(moved.data(), moved.data() + moved.size(), r2, m2, &data_end, &dig2) == n);
+                CHECK(dig2.size() == dig.size() && dig2[0] == dig[0] && dig2[1] != dig[1]);
+                for (size_t k = 2; k < dig.size(); ++k) CHECK(dig2[k] == dig[k]);
+            }
         }
+        unsetenv("PGT_HOST_THREADS");
     }
     {   // 7. HostBuf: malloc below 8 MiB, a 2-MiB-aligned mapping of whole huge pages from there on; every byte writable; release and re-use
         HostBuf h;

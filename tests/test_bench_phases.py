@@ -1,0 +1,94 @@
+"""CPU: bench.py's phase log and watchdog (what makes an unattended N > 1 run fail with a named phase instead of a
+driver timeout), and the self-maintaining roofline.traffic figure."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(body, **env):
+    code = "import sys, time, json\nsys.argv=['bench.py']\nimport bench\n" + textwrap.dedent(body)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120,
+                          env=dict(os.environ, PYTHONPATH=ROOT, **env))
+
+
+def test_phase_overrun_exits_124_and_names_rank_and_phase():
+    r = _run("""
+        ph = bench.Phases(rank=3, world=8, scale=0.02)      # 'roofline': 30 s x 0.02 = 0.6 s
+        with ph("roofline"):
+            time.sleep(30)
+        print("not reached")
+    """)
+    assert r.returncode == 124 and "not reached" not in r.stdout
+    assert "[bench r3/8" in r.stderr and "phase 'roofline' exceeded its deadline" in r.stderr and "exit 124" in r.stderr
+
+
+def test_degradable_phase_prints_the_secured_line_and_exits_0():
+    r = _run("""
+        ph = bench.Phases(rank=0, world=2, scale=0.1)       # 'peer timed': 6 s, rank 0 fires 3 s early
+        ph.secure(lambda why: json.dumps({"secured": True, "why": why}))
+        with ph("peer timed", degradable=True):
+            time.sleep(30)
+    """)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["secured"] is True and "peer timed" in line["why"]
+    r = _run("""
+        ph = bench.Phases(rank=1, world=2, scale=0.02)
+        with ph("peer timed", degradable=True):
+            time.sleep(30)
+    """)
+    assert r.returncode == 0 and r.stdout.strip() == ""     # other ranks leave quietly, code 0
+
+
+def test_phases_in_time_are_logged_and_summed_and_fault_hook_fires():
+    r = _run("""
+        ph = bench.Phases(rank=0, world=1, scale=1.0)
+        for _ in range(2):
+            with ph("columns"):
+                time.sleep(0.05)
+        assert 0.09 < ph.taken["columns"] < 1.0
+        print("fine")
+    """)
+    assert r.returncode == 0 and "fine" in r.stdout and r.stderr.count("columns: done in") == 2
+    r = _run("""
+        ph = bench.Phases(rank=1, world=2, scale=1.0)
+        with ph("gather timed"):
+            pass
+    """, PGT_BENCH_FAULT="1:gather timed:die")
+    assert r.returncode == 17 and "fault injected: die in phase 'gather timed'" in r.stderr
+
+
+def test_every_phase_has_a_deadline_and_the_sum_fits_the_drivers_budget():
+    multi = ("init", "columns", "gather timed", "verify", "roofline")
+    assert sum(bench.PHASE_DEADLINES_S[p] for p in multi) <= 480   # the driver gives the whole command 600 s
+    assert bench.PHASE_DEADLINES_S["peer timed"] + 2 * bench.PHASE_DEADLINES_S["verify"] + sum(
+        bench.PHASE_DEADLINES_S[p] for p in ("init", "columns", "gather timed", "roofline")) <= 600
+
+
+def test_pmc_traffic_follows_the_kernel_source_hash(tmp_path, monkeypatch):
+    """roofline.traffic is the committed PMC figure only while the kernel sources hash to what it was measured on."""
+    path = os.path.join(ROOT, "profiles", "pmc_headline.json")
+    t, why = bench.pmc_traffic(10**8, 1)
+    assert t is None and "headline workload only" in why
+    if os.path.exists(path):
+        rec = json.load(open(path))
+        t, why = bench.pmc_traffic(10**9, 1)
+        if rec["kernel_source_sha256"] == bench.kernel_source_sha256():
+            assert t == rec["traffic_bytes_per_launch"] and 16.0e9 < t < 16.4e9
+            assert abs(t - (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024) < 1
+        else:
+            assert t is None and "other kernel sources" in why
+    # a record measured on other sources is never reported
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    (fake / "pmc_headline.json").write_text(json.dumps({"kernel_source_sha256": "0" * 64, "traffic_bytes_per_launch": 1.0}))
+    (tmp_path / "popgenomicstools_amd").symlink_to(os.path.join(ROOT, "popgenomicstools_amd"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, why = bench.pmc_traffic(10**9, 1)
+    assert t is None and "other kernel sources" in why

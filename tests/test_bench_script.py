@@ -49,10 +49,22 @@ def test_bench_launches_its_own_ranks():
         env.pop(k, None)
     one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
                                env=env, timeout=400))
+    # the default (--exchange auto) is the gather alone: the transport north_star names, nothing opt-in in an unattended run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env,
                        timeout=500)
+    dflt = _line(r)
+    assert dflt["n_gpus"] == 2 and dflt["ok"] is True and dflt["rows_sha256"] == one["rows_sha256"]
+    assert dflt["config"]["row_exchange"] == "gather" and "exchange_peer" not in dflt["extra"]
+    assert "REHEARSAL" in dflt["config"]["collective_backend"]
+    for phase in ("init", "columns", "gather timed", "verify", "roofline"):   # every rank announces every phase on stderr
+        for rk in (0, 1):
+            assert f"[bench r{rk}/2" in r.stderr and f"] {phase}: done in" in r.stderr, (phase, r.stderr[-3000:])
+        assert dflt["extra"]["phase_seconds"][phase] >= 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "both"] + SMALL, capture_output=True,
+                       text=True, env=env, timeout=500)
     two = _line(r)
     assert two["n_gpus"] == 2 and two["rows_check"].startswith("bitwise equal") and two["rows_sha256"] == one["rows_sha256"]
+    assert two["ok"] is True
     ex = two["extra"]
     assert ex["exchange_gather"]["rows_check"] == "bitwise equal" and ex["exchange_gather"]["ms_per_step"] > 0
     assert ex["exchange_peer"]["rows_check"] == "bitwise equal" and ex["exchange_peer"]["ms_per_step"] > 0
@@ -62,3 +74,53 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stepsize", "0"] + SMALL, capture_output=True,
                          text=True, env=env, timeout=300)
     assert bad.returncode != 0
+
+
+def _rehearsal_env(**kw):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PGT_BENCH_BACKEND="gloo", PGT_BENCH_SHARE_GPU="1", **kw)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.timeout(900)
+def test_bench_rank_lost_or_wedged_mid_run_fails_fast_and_names_the_phase():
+    """The first N > 1 run on real hardware is unattended: a rank that dies, or one that never returns from a phase, must
+    end the whole command with a non-zero code well inside the phase deadline and leave the phase's name on stderr."""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    # (a) rank 1 dies at the start of the timed gather
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:gather timed:die",
+                                                                                PGT_BENCH_DEADLINE_SCALE="0.5"), timeout=400)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert "fault injected: die in phase 'gather timed'" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # (b) rank 1 wedges in the timed gather: BOTH ranks' watchdogs name the phase (rank 0 waits in the collective)
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:gather timed:hang",
+                                                                                PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 200, took
+    assert "phase 'gather timed' exceeded its deadline of 15 s" in r.stderr, r.stderr[-3000:]
+    assert "[bench r1/2" in r.stderr and "giving up (exit 124)" in r.stderr
+    # (c) rank 0 wedges while rebuilding the genome for the check
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_rehearsal_env(PGT_BENCH_FAULT="0:verify:hang",
+                                                                                PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
+    assert r.returncode != 0 and "phase 'verify' exceeded its deadline of 30 s" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.timeout(600)
+def test_bench_second_transport_that_never_returns_degrades_to_the_gather_line():
+    """--exchange both: the gather's line is secured before the opt-in peer-store transport starts; a peer phase that
+    overruns its deadline makes rank 0 print that line (peer marked unavailable, with the reason) and the command exit 0."""
+    one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
+                               env=_rehearsal_env(), timeout=400))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "both"] + SMALL, capture_output=True,
+                       text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:peer timed:hang", PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
+    two = _line(r)
+    assert two["config"]["row_exchange"] == "gather" and two["rows_sha256"] == one["rows_sha256"] and two["ok"] is True
+    assert two["extra"]["exchange_gather"]["rows_check"] == "bitwise equal" and two["extra"]["exchange_gather"]["headline"]
+    assert two["extra"]["exchange_peer"]["available"] is False and "deadline" in two["extra"]["exchange_peer"]["why"]
+    assert "second transport abandoned" in two["extra"]["note"]
+    assert "degrading to the result secured before it" in r.stderr

@@ -204,6 +204,42 @@ def test_dxy_known_answers(pgt, ctx):
             assert lines == c["stdout"] and total == c["stderr"]
 
 
+def test_dxy_rows_against_hand_walked_cases(pgt, ctx):
+    """C-ABI rows (window table + dxy kernels) against tests/golden/dxy_hand_walked.json: outputs derived by stepping
+    through dxyWindow.cpp:172-209,282-433 on paper (the walk is in the fixture).  The columns handed to the C-ABI are the
+    sites both files list (the host's merge); where the reference itself mis-pairs or truncates such input the fixture
+    holds the product's documented output (deliberate divergences) next to the reference's."""
+    k = helpers.load_golden("dxy_hand_walked.json")
+    done = 0
+    for c in k["cases"]:
+        names = []
+        for r in c["pop1"]:
+            if not names or names[-1] != r[0]:
+                names.append(r[0])
+        key2 = {(r[0], r[1]): r for r in c["pop2"]}
+        both = [(r, key2[(r[0], r[1])]) for r in c["pop1"] if (r[0], r[1]) in key2]
+        chr_ids = np.array([names.index(a[0]) for a, _ in both], dtype=np.uint32)
+        pos = np.array([a[1] for a, _ in both], dtype=np.uint32)
+        p1 = np.array([a[2] for a, _ in both]); n1 = np.array([a[3] for a, _ in both], dtype=np.int32)
+        p2 = np.array([b[2] for _, b in both]); n2 = np.array([b[3] for _, b in both], dtype=np.int32)
+        sizes = dict(c["sizes"] or [])
+        for r in c["runs"]:
+            want_out, want_err = helpers.hand_walked_product_expectation(c, r)
+            chr_len = None if r["fixedsite"] else np.array([sizes[nm] for nm in names], dtype=np.uint32)
+            res = pgt.dxy_window(chr_ids, pos, p1, p2, n1, n2, r["winsize"], r["stepsize"], c["minind"], r["fixedsite"], chr_len,
+                                 r["skip_missing"], ctx=ctx)
+            lines = "".join(f"{names[int(w['label_run'])]}\t{int(q['start'])}\t{int(q['end'])}\t{helpers.fmt_g(q['sum'])}\t{int(q['neff'])}\t{int(q['nskip'])}\n"
+                            for w, q in zip(res.win, res.rows))
+            total = f"{helpers.fmt_g(res.total['sum'])}\t{int(res.total['neff'])}\t{int(res.total['nskip'])}\n"
+            if r["winsize"] == 0:
+                assert total == want_out and lines == "", c["name"]
+            else:
+                assert lines == want_out, (c["name"], r, lines)
+                assert total == want_err, (c["name"], r, total)
+            done += 1
+    assert done >= 11
+
+
 @pytest.mark.parametrize("fixedsite", [1, 0])
 def test_dxy_vs_oracle_random(pgt, ctx, oracle, fixedsite):
     rng = np.random.default_rng(3 + fixedsite)

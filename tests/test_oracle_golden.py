@@ -103,6 +103,28 @@ def test_dxy_known_answers(oracle, tmp_path):
         assert e.read_text() == c["stderr"]
 
 
+def test_dxy_hand_walked_cases(oracle, tmp_path):
+    """tests/golden/dxy_hand_walked.json: the bp-slot machine (Q1 carry, Q3 leak, ordinary reset, data beyond the size
+    file's length) and the two-file sync (pop2 within pop1, pop1 within pop2, the two ways the reference mis-pairs or
+    truncates) stepped through dxyWindow.cpp by hand, the walk beside each case.  The oracle restates those lines
+    literally, so it must print the walked output byte for byte — INCLUDING where the reference's behaviour is a quirk
+    the product does not follow.  An independent derivation, not a reference-made pin (the grade stays 'unpinned')."""
+    k = helpers.load_golden("dxy_hand_walked.json")
+    assert len(k["cases"]) >= 9 and all(len(c["walk"]) >= 3 for c in k["cases"])
+    n = 0
+    for c in k["cases"]:
+        m1, m2, sz = helpers.write_hand_walked_case(c, k["header"], tmp_path)
+        for r in c["runs"]:
+            o, e = tmp_path / "o.txt", tmp_path / "e.txt"
+            rc = oracle.dxy_text(m1, m2, None if r["fixedsite"] else sz, r["winsize"], r["stepsize"], c["minind"], r["fixedsite"],
+                                 r["skip_missing"], str(o), str(e))
+            assert rc == 0, c["name"]
+            assert o.read_text() == r["stdout"], (c["name"], r, o.read_text())
+            assert e.read_text() == r["stderr"], (c["name"], r, e.read_text())
+            n += 1
+    assert n >= 11
+
+
 def test_dxy_reference_made_cases(oracle, tmp_path):
     """THE PIN of the dxy restatement, where it exists: stdout, the stderr genome-wide line and the exit code of the
     unmodified reference dxyWindow (both window modes, -minind, -skip_missing, nested site sets, gzip input), byte

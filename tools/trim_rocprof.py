@@ -8,7 +8,10 @@ pmc: one row per dispatch and counter of every pgt:: kernel (kernel name shorten
 kept), plus per-kernel summary rows (avg/min/max) — the inputs of roofline.traffic:
     HBM bytes per launch = 2 x FETCH_SIZE x 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced
     read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE x 1024.
-stats: the rocprofv3 --stats summary with torch's kernels dropped except the five largest."""
+stats: the rocprofv3 --stats summary with torch's kernels dropped except the five largest.
+headline <trimmed pmc_counters.csv> <round> <command>: profiles/pmc_headline.json on stdout — the build kernel's average
+    FETCH_SIZE / WRITE_SIZE per dispatch, the HBM bytes per launch they give and the SHA-256 of the kernel sources they
+    were measured on (bench.py reports roofline.traffic from it only while that hash is the tree's)."""
 import csv
 import glob
 import os
@@ -56,5 +59,30 @@ def stats(f):
             other += 1
 
 
+def headline(trimmed, rnd, command):
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("pgt_kernels.hip", "pgt_device.h"):   # = bench.kernel_source_sha256()
+        h.update(open(os.path.join(root, "popgenomicstools_amd", "csrc", f), "rb").read())
+    got = {}
+    for r in csv.reader(open(trimmed)):
+        if len(r) >= 8 and r[0] == "summary" and r[1].startswith("fst_build_kernel"):
+            got[r[3]] = (float(r[5]), int(r[4]), r[1])
+    fetch, nf, kernel = got["FETCH_SIZE"]
+    write, nw, _ = got["WRITE_SIZE"]
+    json.dump({"kernel": kernel, "kernel_source_sha256": h.hexdigest(), "collected": rnd, "command": command,
+               "dispatches": min(nf, nw), "fetch_kib": round(fetch, 1), "write_kib": round(write, 1),
+               "traffic_bytes_per_launch": (2 * round(fetch, 1) + round(write, 1)) * 1024.0,
+               "algorithmic_bytes_per_launch": 16.0e9,
+               "note": "HBM bytes = 2 x FETCH_SIZE KiB (gfx950 reports half of a wide coalesced read; MI355X_MICROARCH.md, "
+                       "HBM / rocprofv3 section) + WRITE_SIZE KiB; separate --pmc passes"}, sys.stdout, indent=1)
+    print()
+
+
 if __name__ == "__main__":
-    {"pmc": pmc, "stats": stats}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "headline":
+        headline(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        {"pmc": pmc, "stats": stats}[sys.argv[1]](sys.argv[2])
