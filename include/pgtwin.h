@@ -304,8 +304,8 @@ int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src,
  * the raw text is copied to the GPU once and parsed there into the structure-of-arrays columns the
  * *_reduce_dev entry points take, together with the chromosome runs pgt_build_windows_* take.
  *   text, len   the lines to parse, in HOST memory (a header line, if any, already skipped by the caller)
- *   tokens      what the whitespace-separated tokens of a line are, in order; tokens[0] must be PGT_TOK_CHR
- *               (2 <= n_tokens <= 8); tokens beyond n_tokens are ignored, as the tools ignore extra columns
+ *   tokens      what the whitespace-separated tokens of a line are, in order; tokens[0] must be PGT_TOK_CHR or PGT_TOK_CHR_PREFIX
+ *               (2 <= n_tokens <= 12); tokens beyond n_tokens are ignored, as the tools ignore extra columns
  * Semantics of the tools' own loops are kept: a blank line ends the data (fstWindow.cpp:125); a last line
  * without newline is accepted; \r counts as blank.  Numbers the kernel cannot convert exactly in one f64
  * operation (more than 15 significant digits, |power of ten| > 22, inf, nan, odd signs) are converted on the
@@ -324,7 +324,10 @@ enum {
     PGT_TOK_F64 = 3,  /* any double */
     PGT_TOK_I8 = 4,   /* integer, clamped to int8 (hetWindow genotype: only >= 0 and == 1 are ever tested) */
     PGT_TOK_I32 = 5,  /* integer, clamped to int32 (MAF nInd) */
-    PGT_TOK_FREQ = 6  /* double that must lie in [0,1] (MAF allele frequency), else the line is an error */
+    PGT_TOK_FREQ = 6, /* double that must lie in [0,1] (MAF allele frequency), else the line is an error */
+    PGT_TOK_CHR_PREFIX = 7 /* as PGT_TOK_CHR (allowed as tokens[0] only), the chromosome being the token UP TO ITS FIRST '_':
+                            * selscan locus ids `chr_position` (extractChr, ihsWindow.cpp:80-92; xpehhWindow.cpp:82-94); a token
+                            * without '_' is the name as a whole.  Added in round 4 (additive: ABI version unchanged) */
 };
 typedef struct pgt_ingest pgt_ingest;
 /* reductions over DEVICE columns (pgt_ingest_column) with the window table and the rows in HOST memory:
@@ -336,6 +339,9 @@ int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, 
 int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1, const double *d_p2,
                         const int32_t *d_n1, const int32_t *d_n2, uint64_t n, int minind,
                         const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, size_t out_bytes, pgt_dxy_total *tot);
+/* ihsWindow.cpp:123-221 / xpehhWindow.cpp:126-232 over device columns (the device-parsed *.norm table) */
+int pgt_extreme_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_score, uint64_t n, int mode, double cutoff,
+                            const pgt_win *win, uint64_t n_win, pgt_ext_row *out, size_t out_bytes);
 /* device column of token `token` -> host (bytes <= rows * element size, else PGT_EARG) */
 int pgt_ingest_download(pgt_ctx *ctx, const pgt_ingest *ing, int token, void *host_dst, size_t bytes);
 int pgt_ingest_text(pgt_ctx *ctx, const char *text, size_t len, const uint8_t *tokens, int n_tokens, pgt_ingest **out);

@@ -47,11 +47,11 @@ SYMBOLS = [
     "pgt_fst_reduce_pairs_dev", "pgt_dxy_het_reduce_dev", "pgt_af_tree_bytes", "pgt_fst_af_reduce_dev", "pgt_set_max_window", "pgt_set_window_step", "pgt_set_profiling", "pgt_last_kernel_ms", "pgt_plan_shards",
     "pgt_dev_alloc", "pgt_dev_free", "pgt_dev_copy", "pgt_dev_upload", "pgt_dev_memory", "pgt_ingest_text_behind", "pgt_ingest_column_base", "pgt_set_typical_window", "pgt_table_hints", "pgt_ingest_blank_before_end",
     "pgt_peer_access", "pgt_rowbuf_create", "pgt_rowbuf_open", "pgt_rowbuf_close", "pgt_rowbuf_read", "pgt_rowbuf_fill",
-    "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
+    "pgt_fst_reduce_cols", "pgt_het_reduce_cols", "pgt_dxy_reduce_cols", "pgt_extreme_reduce_cols", "pgt_ingest_download", "pgt_ingest_text", "pgt_ingest_rows", "pgt_ingest_bad_line", "pgt_ingest_column", "pgt_ingest_runs", "pgt_ingest_free",
     "pgt_wintab_sites", "pgt_wintab_size", "pgt_wintab_first", "pgt_wintab_device", "pgt_wintab_free",
     "pgt_fst_reduce_tab", "pgt_het_reduce_tab", "pgt_dxy_reduce_tab",
 ]
-PGT_TOK_CHR, PGT_TOK_SKIP, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_FREQ = range(7)
+PGT_TOK_CHR, PGT_TOK_SKIP, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_FREQ, PGT_TOK_CHR_PREFIX = range(8)
 
 
 class PgtError(RuntimeError):
@@ -130,6 +130,8 @@ def load() -> C.CDLL:
     lib.pgt_ingest_blank_before_end.argtypes = [vp]
     lib.pgt_fst_reduce_cols.argtypes = [vp, vp, vp, vp, u64, vp, u64, vp, sz]
     lib.pgt_het_reduce_cols.argtypes = [vp, vp, vp, u64, vp, u64, vp, sz]
+    if hasattr(lib, "pgt_extreme_reduce_cols"):  # absent from the older builds tools/lib_ab.py loads side by side
+        lib.pgt_extreme_reduce_cols.argtypes = [vp, vp, vp, u64, i32, C.c_double, vp, u64, vp, sz]
     lib.pgt_dxy_reduce_cols.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, vp, u64, vp, sz, vp]
     lib.pgt_ingest_download.argtypes = [vp, vp, i32, vp, sz]
     lib.pgt_ingest_text.argtypes = [vp, vp, sz, vp, i32, C.POINTER(vp)]

@@ -96,9 +96,13 @@ struct HintScope {
     HintScope(pgt_ctx *c, const pgt_win *win, uint64_t n_win) : ctx(c), saved(c->hints) {
         uint64_t m = 1, typical = 0, step = 0;
         derive_hints(win, n_win, &m, &typical, &step);
-        if (saved.max_window == 0) {  // an explicit hint (the caller knows the whole table) stays, and stands for the typical length too
+        // an explicit hint (the caller knows the whole table: a shard of it arrives here) stays, and stands for the typical
+        // length too — unless THIS table contradicts it (a window longer than the hint: a stale pgt_set_max_window of an
+        // earlier, unrelated table; the query would walk hundreds of nodes of too low a level), then the table speaks
+        if (saved.max_window == 0 || m > saved.max_window) {
             c->hints.max_window = m;
-            if (typical) c->hints.typical_window = typical;
+            c->hints.typical_window = typical;
+            if (saved.max_window != 0) c->hints.window_step = step;  // a stale longest window means a stale step as well
         }
         if (saved.window_step == 0) c->hints.window_step = step;
     }
@@ -516,26 +520,35 @@ int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src,
 
 /* ---------------- host-buffer entry points ---------------- */
 
-int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
-                       const pgt_win *win, uint64_t n_win, pgt_ext_row *out) {
+int pgt_extreme_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_score, uint64_t n, int mode, double cutoff,
+                            const pgt_win *win, uint64_t n_win, pgt_ext_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
-    if ((n && (!pos || !score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    if ((n && (!d_pos || !d_score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    if (int rc = room_check(ctx, "pgt_extreme_reduce_cols", n_win, sizeof(pgt_ext_row), out_bytes)) return rc;
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);
-    DevBuf dpos, ds, dwin, dout, dtree;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = ds.upload(ctx, score, n * sizeof(double), "upload scores")) return rc;
+    DevBuf dwin, dout, dtree;
     if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
     if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_ext_row), "alloc rows")) return rc;
     const size_t tb = pgt_tree_bytes(PGT_STAT_EXT, n);
     if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_extreme_reduce_dev(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(ds.p), n, mode, cutoff,
-                                        static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_ext_row *>(dout.p),
-                                        n_win * sizeof(pgt_ext_row), dtree.p, tb, nullptr))
+    if (int rc = pgt_extreme_reduce_dev(ctx, d_pos, d_score, n, mode, cutoff, static_cast<pgt_win *>(dwin.p), n_win,
+                                        static_cast<pgt_ext_row *>(dout.p), n_win * sizeof(pgt_ext_row), dtree.p, tb, nullptr))
         return rc;
     if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "extreme kernels")) return rc;
     if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_ext_row), hipMemcpyDeviceToHost), "download rows");
     return PGT_OK;
+}
+
+int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
+                       const pgt_win *win, uint64_t n_win, pgt_ext_row *out) {
+    PGT_USE_DEVICE(ctx);
+    if ((n && (!pos || !score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    DevBuf dpos, ds;
+    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
+    if (int rc = ds.upload(ctx, score, n * sizeof(double), "upload scores")) return rc;
+    return pgt_extreme_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(ds.p), n, mode, cutoff, win, n_win, out,
+                                   (size_t)n_win * sizeof(pgt_ext_row));
 }
 
 

@@ -40,7 +40,7 @@ namespace {
 constexpr int kLaneBytes = 16;
 constexpr int kBlockThreads = 256;
 constexpr uint64_t kBlockBytes = (uint64_t)kLaneBytes * kBlockThreads;  // 4 KiB of text per workgroup
-constexpr int kMaxTokens = 8;
+constexpr int kMaxTokens = 12;  // xpehhWindow: id pos + 7 numeric fields, the score in the last
 constexpr uint32_t kListCap = 1u << 20;  // slow lines / run starts the device may report before the host takes over
 constexpr uint64_t kMaxLine = 1u << 16;  // a lane never walks further than this through one line: longer lines (not
                                          // the tools' tables) make the ingest refuse the input (PGT_EDOMAIN), the
@@ -49,6 +49,7 @@ constexpr uint64_t kMaxLine = 1u << 16;  // a lane never walks further than this
 struct Spec {
     uint8_t tok[kMaxTokens];
     int n;
+    int chr_prefix;  // tokens[0] == PGT_TOK_CHR_PREFIX: the chromosome is the first token up to its first '_'
 };
 struct ListEntry {  // a run start (name token) or a slow line (line start)
     uint64_t row, off;
@@ -208,6 +209,13 @@ __device__ __forceinline__ void append(ListEntry *list, uint32_t *n, uint64_t ro
     if (k < kListCap) list[k] = ListEntry{row, off, len, 0u};
 }
 
+// selscan locus ids `chr_position`: the chromosome is the id up to its first '_' (extractChr, ihsWindow.cpp:80-92)
+__device__ __forceinline__ Token chr_prefix(const char *txt, Token t) {
+    for (uint64_t q = t.b; q < t.e; ++q)
+        if (txt[q] == '_') return Token{t.b, q};
+    return t;
+}
+
 __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t row, const Spec &spec, const Columns &cols,
                            Counters *cnt, ListEntry *runs, ListEntry *slow) {
     uint64_t p = s;
@@ -221,6 +229,7 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
         atomicMin(&cnt->first_empty, (unsigned long long)row);
         return;
     }
+    if (spec.chr_prefix) chr = chr_prefix(txt, chr);  // may be empty ("_123"): an empty name is a name like any other
     // run start?  compare the chromosome token with the previous line's
     bool new_run = row == 0;
     if (!new_run) {
@@ -232,7 +241,8 @@ __device__ void parse_line(const char *txt, uint64_t len, uint64_t s, uint64_t r
             return;
         }
         uint64_t pp = q;
-        const Token prev = next_token(txt, pp, s - 1, s - 1);
+        Token prev = next_token(txt, pp, s - 1, s - 1);
+        if (spec.chr_prefix) prev = chr_prefix(txt, prev);
         new_run = prev.e - prev.b != chr.e - chr.b;
         for (uint64_t k = 0; !new_run && k < chr.e - chr.b; ++k) new_run = txt[prev.b + k] != txt[chr.b + k];
     }
@@ -389,8 +399,8 @@ int ingest_fail(std::string *err, int code, const std::string &msg) {
 namespace pgt {
 
 int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens, int n_tokens, uint64_t front, pgt_ingest **out, std::string *err) {
-    if (!out || (len && !text) || !tokens || n_tokens < 2 || n_tokens > kMaxTokens || tokens[0] != PGT_TOK_CHR)
-        return ingest_fail(err, PGT_EARG, "pgt_ingest_text: bad argument (the first token must be PGT_TOK_CHR, 2..8 tokens)");
+    if (!out || (len && !text) || !tokens || n_tokens < 2 || n_tokens > kMaxTokens || (tokens[0] != PGT_TOK_CHR && tokens[0] != PGT_TOK_CHR_PREFIX))
+        return ingest_fail(err, PGT_EARG, "pgt_ingest_text: bad argument (the first token must be PGT_TOK_CHR or PGT_TOK_CHR_PREFIX, 2..12 tokens)");
     for (int k = 1; k < n_tokens; ++k)
         if (tokens[k] == PGT_TOK_CHR || tokens[k] > PGT_TOK_FREQ)
             return ingest_fail(err, PGT_EARG, "pgt_ingest_text: unknown token kind");
@@ -453,6 +463,7 @@ int ingest_text(int device, const char *text, size_t len, const uint8_t *tokens,
     // 3. columns + parse
     Spec spec{};
     spec.n = n_tokens;
+    spec.chr_prefix = tokens[0] == PGT_TOK_CHR_PREFIX;
     Columns cols{};
     for (int k = 0; k < n_tokens; ++k) {
         spec.tok[k] = tokens[k];

@@ -147,7 +147,24 @@ struct NodeStage {
         if (++held == STAGE) flush();
     }
 };
-template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true>  // UNROLL: loads in flight per lane (one column at a time)
+// 64 KiB of one column of a level-2 tile -> the 64 leaf sums, lane j keeps leaf j's; U loads in flight per lane
+template <int U>
+__device__ __forceinline__ void fst_column_sums(const double2 *__restrict__ p, int lane, double &keep) {
+#pragma unroll 1
+    for (int j = 0; j < kRadix; j += U) {
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load16<true>(p + (j + u) * kWave + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double s = wave_sum(v[u].x + v[u].y);
+            if (lane == j + u) keep = s;
+        }
+    }
+}
+// UNROLL: loads in flight per lane (one column at a time).  TAIL_UNROLL / TAIL_SCOPE (tuning): the queue depth of a wave's LAST
+// tile (scope 2: both columns, 1: only `b`, 0: off) — during the last round ever fewer waves are left to keep the HBM busy.
+template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true, int TAIL_UNROLL = UNROLL, int TAIL_SCOPE = 0>
 __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv, uint64_t t_begin = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -167,28 +184,11 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
         if (base + kTile2 <= n) {
             const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(a + base);
             const double2 *__restrict__ pb = reinterpret_cast<const double2 *>(b + base);
-#pragma unroll 1
-            for (int j = 0; j < kRadix; j += UNROLL) {  // the tile's 64 KiB of `a` ...
-                double2 v[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = load16<true>(pa + (j + u) * kWave + lane);
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const double sa = wave_sum(v[u].x + v[u].y);
-                    if (lane == j + u) keep_a = sa;
-                }
-            }
-#pragma unroll 1
-            for (int j = 0; j < kRadix; j += UNROLL) {  // ... then its 64 KiB of `b`
-                double2 v[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = load16<true>(pb + (j + u) * kWave + lane);
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const double sb = wave_sum(v[u].x + v[u].y);
-                    if (lane == j + u) keep_b = sb;
-                }
-            }
+            const bool last = TAIL_SCOPE != 0 && t + n_waves >= n_l2;  // wave-uniform: this wave's last tile
+            if (TAIL_SCOPE == 2 && last) fst_column_sums<TAIL_UNROLL>(pa, lane, keep_a);
+            else fst_column_sums<UNROLL>(pa, lane, keep_a);  // the tile's 64 KiB of `a` ...
+            if (TAIL_SCOPE != 0 && last) fst_column_sums<TAIL_UNROLL>(pb, lane, keep_b);
+            else fst_column_sums<UNROLL>(pb, lane, keep_b);  // ... then its 64 KiB of `b`
         } else {
             for (int j = 0; j < kRadix; ++j) {
                 const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;

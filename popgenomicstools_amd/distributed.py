@@ -226,13 +226,16 @@ class RowExchange:
             self.peer_error, ok = "self-test store: " + str(e), 0
         dist.barrier(group=self.group)  # every rank's stores have completed on its side
         if self.rank == self.dst and ok:
-            raw = self.ctx.rowbuf_read(self.buf, self.total)
-            for r in range(self.world):
-                nw = self.counts[r] * self.row_bytes // 8
-                got = raw[self.offsets[r]: self.offsets[r] + 8 * nw].view(np.uint64)
-                if not np.array_equal(got, self.ctx.pattern_words(nw, 1000 + r)):
-                    self.peer_error, ok = f"self-test: the pattern rank {r} stored did not arrive in rank {self.dst}'s buffer", 0
-                    break
+            try:  # a failing read-back must not keep this rank out of the all_reduce below (every other rank waits there)
+                raw = self.ctx.rowbuf_read(self.buf, self.total)
+                for r in range(self.world):
+                    nw = self.counts[r] * self.row_bytes // 8
+                    got = raw[self.offsets[r]: self.offsets[r] + 8 * nw].view(np.uint64)
+                    if not np.array_equal(got, self.ctx.pattern_words(nw, 1000 + r)):
+                        self.peer_error, ok = f"self-test: the pattern rank {r} stored did not arrive in rank {self.dst}'s buffer", 0
+                        break
+            except PgtError as e:
+                self.peer_error, ok = "self-test read-back: " + str(e), 0
         flag = torch.tensor([ok], dtype=torch.int32, device=self.coll_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag.item()) == 1

@@ -941,7 +941,7 @@ inline bool ends_with_blank_line(const char *b, const char *e) {
 // `runs` (stitched at the seams) describe the table, *n_rows its length; false: some piece was refused by the device
 // parser (too many irregular lines) — parse on the host.  Text errors die with the host parser's message.
 inline bool ingest_on_devices(DeviceOpener &device, const char *b, const char *e, const uint8_t *spec, int n_tokens, const char *what,
-                              const char *path, std::vector<DevicePiece> &pieces, Runs &runs, size_t *n_rows) {
+                              const char *path, std::vector<DevicePiece> &pieces, Runs &runs, size_t *n_rows, size_t first_line_no = 1) {
     const size_t N = device.count();
     const std::vector<const char *> cut = cut_at_lines(b, e, N);
     std::vector<pgt_ingest *> ing(N, nullptr);
@@ -968,7 +968,7 @@ inline bool ingest_on_devices(DeviceOpener &device, const char *b, const char *e
     for (size_t k = 0; k < N; ++k) {
         if (!ing[k]) continue;
         const int64_t bad = pgt_ingest_bad_line(ing[k]);
-        if (bad >= 0) die(std::string(what) + " on line " + std::to_string(1 + row + (uint64_t)bad) + " of " + path);
+        if (bad >= 0) die(std::string(what) + " on line " + std::to_string(first_line_no + row + (uint64_t)bad) + " of " + path);
         const uint64_t rows = pgt_ingest_rows(ing[k]);
         const uint64_t *len = nullptr, *off = nullptr;
         const uint32_t *nlen = nullptr;

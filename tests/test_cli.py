@@ -66,6 +66,15 @@ def test_unparsable_line_is_refused(hosts, tmp_path):
     f.write_text("c1\t1\t0.1\t0.2\nc1\t2\tnan_or_header\t0.2\n")
     r = run([hosts["fstWindow"], str(f), "1", "1"])
     assert r.returncode == 255 and "line 2" in r.stderr  # the reference would reuse stale values (Q12)
+    # a MAF frequency outside [0, 1]: the reference computes a negative dxy that its windows neither add nor count as skipped
+    # (dxyWindow.cpp:180-185) while the genome-wide line adds and counts it (:382-385); here the line is refused, nothing printed
+    # 
+    hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd\n"
+    m1, m2 = tmp_path / "p1.mafs", tmp_path / "p2.mafs"
+    m1.write_text(hdr + "cA\t1\tA\tC\tA\t0.5\t4\ncA\t2\tA\tC\tA\t1.5\t4\n")
+    m2.write_text(hdr + "cA\t1\tA\tC\tA\t0.5\t4\ncA\t2\tA\tC\tA\t0.5\t4\n")
+    r = run([hosts["dxyWindow"], "-winsize", "1", "-stepsize", "1", "-fixedsite", "1", str(m1), str(m2)])
+    assert r.returncode == 255 and r.stdout == "" and "cannot parse MAF line" in r.stderr and "freq in [0,1]" in r.stderr
 
 
 def test_no_window_input_prints_nothing(hosts, tmp_path):
@@ -344,6 +353,69 @@ def test_extreme_cli_against_reference_goldens(hosts_ext, tmp_path):
         r = run(argv)
         assert r.returncode == 0, r.stderr
         assert r.stdout == c["stdout"], c["args"]  # selections and integer ratios: byte-identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_extra", [{"PGT_GPU_INGEST": "1"}, {"PGT_DEVICES": "0,0"}, {"PGT_DEVICES": "0,0,0", "PGT_GPU_INGEST": "1"}])
+def test_extreme_cli_device_parser_and_several_gpus_print_the_reference_tsv(hosts_ext, tmp_path, env_extra):
+    """ihsWindow / xpehhWindow with the table parsed on the GPU (the locus id's `chr_` prefix is the device parser's
+    PGT_TOK_CHR_PREFIX; only the positions come back for the window rules) and over two / three contexts (text cut per
+    context, window blocks from pgt_plan_shards): all 140 reference-made cases, stdout byte for byte as with the host
+    parser on one GPU (ihsWindow.cpp:123-221, xpehhWindow.cpp:126-232)."""
+    cases = helpers.load_golden("ref_extreme.json")["cases"]
+    assert len(cases) >= 100
+    for c in cases:
+        paths = {}
+        for name, text in c["files"].items():
+            p = tmp_path / name
+            p.write_text(text)
+            paths[name] = str(p)
+        argv = [hosts_ext[c["tool"]]] + [paths[a[1:]] if a.startswith("@") else a for a in c["args"]]
+        r = run(argv, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, (c["args"], r.stderr)
+        assert r.stdout == c["stdout"], (c["args"], env_extra)
+
+
+@pytest.mark.gpu
+def test_extreme_cli_large_table_all_paths_agree_and_errors_keep_their_line_numbers(hosts_ext, tmp_path):
+    """A generated 2 * 10^6-line *.norm table (7 chromosomes, ties, runs of empty windows): host parser on one GPU ==
+    device parser == two and three contexts with either parser, for both tools; a bad line deep in the table is reported
+    with its line number by every path (xpehhWindow counts its header line); an input beyond the device's memory is
+    refused with nothing printed (the extreme-score tools have no passes mode)."""
+    rng = np.random.default_rng(31)
+    n = 2_000_000
+    chrom = np.sort(rng.integers(1, 8, n))
+    pos = np.zeros(n, dtype=np.int64)
+    for c in range(1, 8):
+        m = chrom == c
+        pos[m] = np.cumsum(rng.integers(1, 400, int(m.sum())))
+    score = np.round(rng.normal(0, 1.2, n), 4)
+    score[rng.integers(0, n, 2000)] = 2.5   # ties: the first occurrence wins
+    lines = [f"chr{c}_{p}\t{p}\t0.3\t1.1\t2.2\t0.5\t{s}\t0\n" for c, p, s in zip(chrom.tolist(), pos.tolist(), score.tolist())]
+    ihs = tmp_path / "big.ihs.norm"
+    ihs.write_text("".join(lines))
+    xp = tmp_path / "big.xpehh.norm"
+    xp.write_text("id\tpos\tgpos\tp1\tihh1\tp2\tihh2\txpehh\tnormxpehh\tcrit\n" +
+                  "".join(f"chr{c}_{p}\t{p}\t0.1\t0.3\t1.1\t0.4\t2.2\t0.5\t{s}\t0\n" for c, p, s in zip(chrom.tolist(), pos.tolist(), score.tolist())))
+    envs = [{"PGT_GPU_INGEST": "0"}, {"PGT_GPU_INGEST": "1"}, {"PGT_GPU_INGEST": "0", "PGT_DEVICES": "0,0"},
+            {"PGT_GPU_INGEST": "1", "PGT_DEVICES": "0,0"}, {"PGT_GPU_INGEST": "1", "PGT_DEVICES": "0,0,0"}]
+    for argv in ([hosts_ext["ihsWindow"], str(ihs), "-winsize", "50000", "-cutoff", "2"],
+                 [hosts_ext["xpehhWindow"], str(xp), "2", "-winsize", "30000"]):
+        outs = [run(argv, env=dict(os.environ, **e)) for e in envs]
+        assert outs[0].returncode == 0 and len(outs[0].stdout.splitlines()) > 1000
+        for e, r in zip(envs[1:], outs[1:]):
+            assert (r.returncode, r.stdout) == (0, outs[0].stdout), (argv[0], e, r.stderr[-500:])
+    # a bad line at line 1 500 001 of the data
+    bad_at = 1_500_000
+    lines_bad = list(lines)
+    lines_bad[bad_at] = lines_bad[bad_at].replace("\t0.5\t", "\t0.5\tnot_a_number_")
+    ihs.write_text("".join(lines_bad))
+    for e in envs:
+        r = run([hosts_ext["ihsWindow"], str(ihs), "-winsize", "50000"], env=dict(os.environ, **e))
+        assert r.returncode == 255 and r.stdout == "" and f"line {bad_at + 1} of" in r.stderr, (e, r.stderr[-300:])
+    ihs.write_text("".join(lines))
+    r = run([hosts_ext["ihsWindow"], str(ihs)], env=dict(os.environ, PGT_MAX_RESIDENT_SITES="100000"))
+    assert r.returncode == 255 and r.stdout == "" and "no passes mode" in r.stderr
 
 
 @pytest.mark.gpu

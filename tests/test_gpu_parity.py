@@ -610,6 +610,35 @@ def test_af_front_end_vs_oracle(pgt, ctx, oracle, n_pops, n, W, S):
     assert p == rows.shape[0]
 
 
+def test_af_front_end_against_exact_rational_evaluation(pgt, ctx):
+    """The device AF front end against tests/golden/wcfst_exact.json (betaAFOutlier.R:400-418,440-446 in exact rationals,
+    tests/golden/make_wcfst_exact.py): per-site windows give (a, a+b) of every site, one window over all sites gives
+    genomeFst — no oracle in between.  Tolerance 1e-9 relative to the component's scale (north_star's bound)."""
+    from fractions import Fraction
+    k = helpers.load_golden("wcfst_exact.json")
+    for c in k["cases"]:
+        n = len(c["sites"])
+        f1 = np.array([float(Fraction(s["f1"])) for s in c["sites"]])
+        f2 = np.array([float(Fraction(s["f2"])) for s in c["sites"]])
+        pos = np.arange(1, n + 1, dtype=np.uint32)
+        runs = np.array([n], dtype=np.uint64)
+        per_site = _af_rows(ctx, pos, [f1, f2], [float(c["n1"]), float(c["n2"])], pgt.build_windows_sites(runs, 1, 1))[0]
+        ea = np.array([s["a_f64"] for s in c["sites"]])
+        eab = np.array([s["a_plus_b_f64"] for s in c["sites"]])
+        scale = np.maximum(np.abs(eab), np.abs(ea))
+        assert per_site.size == n
+        assert np.all(np.abs(per_site["bsum"] - eab) <= 1e-9 * scale + 1e-15), per_site["bsum"] - eab
+        assert np.all(np.abs(per_site["asum"] - ea) <= 1e-9 * scale + 1e-15), per_site["asum"] - ea
+        whole = _af_rows(ctx, pos, [f1, f2], [float(c["n1"]), float(c["n2"])], pgt.build_windows_sites(runs, n, n))[0]
+        assert whole.size == 1 and int(whole["n"][0]) == n
+        assert abs(float(whole["fst"][0]) - c["genome_fst_f64"]) <= 1e-9
+        # the same two columns among eight populations: pair (0, 1) of 28 must not change
+        rng = np.random.default_rng(5)
+        others = [np.round(rng.uniform(0, 1, n), 6) for _ in range(6)]
+        eight = _af_rows(ctx, pos, [f1, f2] + others, [float(c["n1"]), float(c["n2"])] + [9.0] * 6, pgt.build_windows_sites(runs, n, n))
+        assert abs(float(eight[0]["fst"][0]) - c["genome_fst_f64"]) <= 1e-9
+
+
 def test_af_front_end_equals_component_path(pgt, ctx, oracle):
     """Feeding the restated (a, a+b) columns through the ordinary fst path gives the same rows (1e-9)."""
     rng = np.random.default_rng(77)

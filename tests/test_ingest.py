@@ -9,14 +9,17 @@ import pytest
 
 import synth
 from popgenomicstools_amd import _lib
-from popgenomicstools_amd._lib import (PGT_TOK_CHR, PGT_TOK_F64, PGT_TOK_FREQ, PGT_TOK_I8, PGT_TOK_I32, PGT_TOK_SKIP,
-                                       PGT_TOK_U32)
+from popgenomicstools_amd._lib import (PGT_TOK_CHR, PGT_TOK_CHR_PREFIX, PGT_TOK_F64, PGT_TOK_FREQ, PGT_TOK_I8, PGT_TOK_I32,
+                                       PGT_TOK_SKIP, PGT_TOK_U32)
 
 pytestmark = pytest.mark.gpu
 
 FST = [PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_F64, PGT_TOK_F64]
 HET = [PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_I8]
 MAF = [PGT_TOK_CHR, PGT_TOK_U32, PGT_TOK_SKIP, PGT_TOK_SKIP, PGT_TOK_SKIP, PGT_TOK_FREQ, PGT_TOK_I32]
+# selscan *.norm: locus id `chr_position`, position, numeric fields; the score is field 4 (iHS) or 6 (XP-EHH) behind the position
+IHS = [PGT_TOK_CHR_PREFIX, PGT_TOK_U32] + [PGT_TOK_SKIP] * 4 + [PGT_TOK_F64]
+XPEHH = [PGT_TOK_CHR_PREFIX, PGT_TOK_U32] + [PGT_TOK_SKIP] * 6 + [PGT_TOK_F64]
 
 _F64 = re.compile(rb"-?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?$|-?(inf|infinity|nan)$", re.I)  # std::from_chars, general format
 _INT = re.compile(rb"-?\d+$")
@@ -50,7 +53,7 @@ def _int(tok, lo, hi, clamp):
 
 def host_model(text: bytes, tokens):
     """-> (rows per stored token, run names, run lengths, bad_line or -1)"""
-    cols = {k: [] for k, t in enumerate(tokens) if t not in (PGT_TOK_CHR, PGT_TOK_SKIP)}
+    cols = {k: [] for k, t in enumerate(tokens) if t not in (PGT_TOK_CHR, PGT_TOK_CHR_PREFIX, PGT_TOK_SKIP)}
     names, lens, bad = [], [], -1
     lines = text.split(b"\n")
     if lines and lines[-1] == b"":
@@ -86,8 +89,9 @@ def host_model(text: bytes, tokens):
             break
         for k, v in vals.items():
             cols[k].append(v)
-        if not names or names[-1] != toks[0]:
-            names.append(toks[0])
+        name = toks[0].split(b"_", 1)[0] if tokens[0] == PGT_TOK_CHR_PREFIX else toks[0]  # extractChr, ihsWindow.cpp:80-92
+        if not names or names[-1] != name:
+            names.append(name)
             lens.append(0)
         lens[-1] += 1
     return cols, [n.decode("latin-1") for n in names], lens, bad
@@ -298,3 +302,30 @@ def test_text_beyond_4_gib(ctx):
         assert np.array_equal(got[0].view(np.uint8), want.view(np.uint8))       # the bits of the first block
         assert (got == got[0]).all()                                            # ... and of every repeat
     ing.free()
+
+
+def test_locus_id_prefix_names_the_chromosome(ctx):
+    """PGT_TOK_CHR_PREFIX (round 4; ihsWindow / xpehhWindow): the run name is the first token up to its first '_'
+    (extractChr, ihsWindow.cpp:80-92) — ids that differ only behind the '_' stay in one run, an id without '_' is the name
+    as a whole, an id that starts with '_' gives the empty name; everything else as with PGT_TOK_CHR."""
+    rng = np.random.default_rng(12)
+    n = 300_000
+    chr_ids, pos = synth.chromosomes(rng, n, 11, equal=False)
+    sc = np.round(rng.normal(0, 1, n), 5)
+    text = "".join(f"chr{c}_{p}\t{p}\t0.2\t1.5\t2.5\t0.1\t{v}\t1\n" for c, p, v in zip(chr_ids, pos, sc)).encode()
+    assert check(ctx, text, IHS) == n
+    ing = ctx.ingest_text(text, IHS)
+    assert ing.run_names == [f"chr{c}" for c in range(11)]
+    ing.free()
+    text = "".join(f"sc{c}_{p}_x\t{p}\t1\t2\t3\t4\t5\t6\t{v}\textra\n" for c, p, v in zip(chr_ids, pos, sc)).encode()
+    assert check(ctx, text, XPEHH) == n
+    odd = (b"chr1_5\t5\t0\t0\t0\t0\t1.5\n" b"chr1_9_b\t9\t0\t0\t0\t0\t-2\n" b"chr1\t11\t0\t0\t0\t0\t3\n"   # one run: chr1
+           b"chr10_1\t1\t0\t0\t0\t0\t1e-3\n" b"_7\t7\t0\t0\t0\t0\t4\n" b"_\t8\t0\t0\t0\t0\t4\n"                 # chr10, then the empty name twice
+           b"chrX_1\t1\t0\t0\t0\t0\t+1.25E+1\n" b"chrX_2\t2\t0\t0\t0\t0\tnan\n")
+    check(ctx, odd, IHS)
+    ing = ctx.ingest_text(odd, IHS)
+    assert ing.run_names == ["chr1", "chr10", "", "chrX"] and ing.run_len.tolist() == [3, 1, 2, 2]
+    ing.free()
+    for bad_tokens in ([PGT_TOK_U32, PGT_TOK_U32], [PGT_TOK_CHR, PGT_TOK_CHR_PREFIX], [PGT_TOK_CHR_PREFIX] + [PGT_TOK_SKIP] * 12):
+        with pytest.raises(_lib.PgtError):
+            ctx.ingest_text(b"a 1\n", bad_tokens)

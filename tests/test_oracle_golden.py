@@ -321,3 +321,27 @@ def test_dxy_bp_mode_equals_independent_slot_model(oracle):
             assert abs(m[3] - r["value"]) <= 1e-12
         n_win += rows.size
     assert n_win > 3000
+
+
+def test_wcfst_restatement_against_exact_rational_evaluation(oracle):
+    """orc_wcfst_site (the C restatement of betaAFOutlier.R:400-418 the AF front end is checked against) vs
+    tests/golden/wcfst_exact.json: the same R lines evaluated in exact rational arithmetic (make_wcfst_exact.py).  A third
+    derivation, not a reference-made pin (no R here): per site both components to a few ulps of the component's scale
+    (`a` cancels towards 0 where the populations agree, so its error is measured against a+b's magnitude), and the
+    genome-wide ratio (genomeFst, :440-446) to 1e-12."""
+    from fractions import Fraction
+    k = helpers.load_golden("wcfst_exact.json")
+    assert len(k["cases"]) == 3
+    for c in k["cases"]:
+        f1 = np.array([float(Fraction(s["f1"])) for s in c["sites"]])
+        f2 = np.array([float(Fraction(s["f2"])) for s in c["sites"]])
+        a, ab = oracle.wcfst_columns(f1, f2, c["n1"], c["n2"])
+        ea = np.array([s["a_f64"] for s in c["sites"]])
+        eab = np.array([s["a_plus_b_f64"] for s in c["sites"]])
+        for s in c["sites"]:  # the stored doubles are the correctly rounded fractions
+            assert float(Fraction(s["a"])) == s["a_f64"] and float(Fraction(s["a_plus_b"])) == s["a_plus_b_f64"]
+        scale = np.maximum(np.abs(eab), np.abs(ea)) + 1e-300
+        assert np.all(np.abs(ab - eab) <= 1e-12 * scale + 1e-15), (c["n1"], c["n2"], ab - eab)
+        assert np.all(np.abs(a - ea) <= 1e-12 * scale + 1e-15), (c["n1"], c["n2"], a - ea)
+        assert abs(a.sum() / ab.sum() - c["genome_fst_f64"]) <= 1e-12
+        assert float(Fraction(c["sum_a"]) / Fraction(c["sum_a_plus_b"])) == c["genome_fst_f64"]

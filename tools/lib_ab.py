@@ -66,6 +66,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx_b = pgt.Context(0)  # the tree's library
     _lib._lib, _lib.LIB_PATH = None, old
+    _lib.SYMBOLS = [x for x in _lib.SYMBOLS if x != "pgt_extreme_reduce_cols"]  # added in round 4: an older build lacks it, no config here calls it
     ctx_a = pgt.Context(0)
     assert ctx_a._lib is not ctx_b._lib
     for c in (ctx_a, ctx_b):
@@ -79,16 +80,31 @@ def main():
     out = torch.empty(4 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev)
     p1, p2, n1, n2 = genome.dxy_columns_t(0, n, dev)
     g1, g2 = genome.genotype_t(0, 0, n, dev), genome.genotype_t(1, 0, n, dev)
+    from popgenomicstools_amd._lib import PGT_EXT_IHS
+    score = a * 40.0 - 2.0
+    ewin_h = pgt.build_windows_extreme(pos.cpu().numpy().view(np.uint32), genome.run_len, None, 100_000)
+    ewin = windows_to_device(ewin_h, dev)
+    fr = [genome.freq_t(k, 0, n, dev) for k in range(8)] if n <= 300_000_000 else None
+    nsamp = [10.0 + k for k in range(8)]
+    af_tree = torch.empty(int(_lib.load().pgt_af_tree_bytes(8, n)), dtype=torch.uint8, device=dev) if fr else None
+    af_out = torch.empty(28 * 40 * (win.numel() // 32), dtype=torch.uint8, device=dev) if fr else None
     configs = [
         ("fstWindow", 16, lambda c: c.fst_reduce_dev(pos, a, b, win, out=out, tree=tree)),
         ("dxyWindow (with the genome-wide line)", 24, lambda c: c.dxy_reduce_dev(pos, p1, p2, n1, n2, 5, win, out=out, tree=tree)),
         ("hetWindow", 1, lambda c: c.het_reduce_dev(pos, g1, win, out=out, tree=tree)),
         ("dxy + het x2 fused", 26, lambda c: c.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree)),
+        ("extreme score (100 kb windows)", 8, lambda c: c.extreme_reduce_dev(pos, score, PGT_EXT_IHS, 2.0, ewin, out=out, tree=tree)),
     ]
+    if fr:
+        configs.append(("AF front end, 8 populations", 64, lambda c: c.fst_af_reduce_dev(pos, fr, nsamp, win, out=af_out, tree=af_tree)))
+        configs.append(("AF front end, 2 populations", 16, lambda c: c.fst_af_reduce_dev(pos, fr[:2], nsamp[:2], win, out=af_out, tree=af_tree)))
     print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A, {BURST} call(s) per measurement\n")
     print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms | step B - A paired |")
     print("|---|---|---|---|---|---|---|---|---|")
+    emax = int((ewin_h["hi"] - ewin_h["lo"]).max())
     for name, bps, fn in configs:
+        for c in (ctx_a, ctx_b):
+            c.set_max_window(emax if name.startswith("extreme") else 50_000)
         for c in (ctx_a, ctx_b, ctx_a, ctx_b):
             one(c, fn)
         ra, rb, diff, sdiff = [], [], [], []

@@ -25,7 +25,7 @@ def main():
     tree = torch.empty(ctx.tree_bytes(0, nmax), dtype=torch.uint8, device=dev)
     sizes = [int(float(x)) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else
                                      "1e6,1e7,2e7,5e7,1e8,1.25e8,2e8,5e8,1e9".split(","))]
-    # tuning build only: variants of the deferred-store kernel, "stage:unroll:nt_stores:grid cap" (PGT_TUNE_BUILD_DEFER)
+    # tuning build only: the product kernel template with other parameters, "stage:loads in flight:workgroups" (PGT_TUNE_FST)
     variants = os.environ.get("SWEEP_VARIANTS", "").split(",") if os.environ.get("SWEEP_VARIANTS") else [""]
     print("| variant | sites | build ms (median of 15) | GB/s | % of 8 TB/s |")
     print("|---|---|---|---|---|")
@@ -36,7 +36,7 @@ def main():
         for r in range(18):
             for v in variants:
                 if v:
-                    os.environ["PGT_TUNE_BUILD_DEFER"] = v
+                    os.environ["PGT_TUNE_FST"] = v
                 ctx.fst_reduce_dev(pos[:n], a[:n], b[:n], win, tree=tree)
                 bm, _ = ctx.last_kernel_ms()
                 if r >= 3:

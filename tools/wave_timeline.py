@@ -1,7 +1,5 @@
 """Where does the fixed cost of a build launch go?  Tuning build only (PGT_EXTRA_HIPCC_FLAGS=-DPGT_TUNING_BUILD):
-runs the stamped copy of the fst build kernel (tools/pgt_build_experiments.inc) with the static tile stride of the
-round-2 product and with tiles handed out by an atomic ticket counter (dyn; dyn2 / dyn4 = half / quarter tiles, timing
-only), and prints per input size the distribution over waves of the end time (relative to the earliest wave start,
+runs the stamped copy of the fst build kernel (tools/pgt_build_experiments.inc) and prints per input size the distribution over waves of the end time (relative to the earliest wave start,
 microseconds, s_memrealtime at 100 MHz), the tiles a wave took, and the mean end time per XCD.
 
     python tools/wave_timeline.py [sizes...]      default 1e8 1.25e8 1e9"""
@@ -26,7 +24,7 @@ for n in sizes:
     win = windows_to_device(pgt.build_windows_sites(np.array([n], dtype=np.uint64), 50_000, 10_000), dev)
     tree = torch.empty(ctx.tree_bytes(PGT_STAT_FST, n), dtype=torch.uint8, device=dev)
     ref = None
-    for mode in ("product", "static", "dyn", "dyn2", "dyn4", "dyn_u8"):
+    for mode in ("product", "stamped"):
         if mode == "product":
             os.environ.pop("PGT_TUNE_BUILD_STAMPS", None)
             ctx.set_profiling(True)
@@ -37,17 +35,16 @@ for n in sizes:
             ctx.set_profiling(False)
             ref = out.clone()
             ms = float(np.median(ev[2:]))
-            print(f"| {n:.3g} | product (round 2 kernel) | | | | | {ms:.4f} | {16.0 * n / ms / 1e6 / 80:.1f} | |", flush=True)
+            print(f"| {n:.3g} | product (unstamped) | | | | | {ms:.4f} | {16.0 * n / ms / 1e6 / 80:.1f} | |", flush=True)
             continue
         os.environ["PGT_TUNE_BUILD_STAMPS"] = path
-        os.environ["PGT_TUNE_BUILD_STAMPS_MODE"] = mode
         kms = []
         for _ in range(6):
             out, _ = ctx.fst_reduce_dev(pos, a, b, win, tree=tree)
             torch.cuda.synchronize()
             raw = np.fromfile(path, dtype=np.uint64)
             kms.append(float(raw[2:3].view(np.float64)[0]))
-        same = bool(torch.equal(out, ref)) if mode in ("static", "dyn", "dyn_u8") else None
+        same = bool(torch.equal(out, ref))
         nw = int(raw[0])
         st = raw[3:].reshape(nw, 6)
         t = st[:, :4].astype(np.int64)
