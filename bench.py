@@ -218,6 +218,7 @@ from popgenomicstools_amd.distributed import RowExchange  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
 
+PREWARM_S = 0.5      # about this many seconds of untimed steps before the warm-up steps of every timed region (config.prewarm_steps)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
 BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
 SEED = 12345
@@ -464,6 +465,7 @@ def bring_up_collectives(world, rank, dev, ph):
 
     def probe():
         try:
+            torch.cuda.set_device(dev)  # the current device is per thread
             g = dist.new_group(backend="nccl", timeout=timedelta(minutes=30), device_id=dev)  # nccl == RCCL on ROCm
             t = torch.ones(1, dtype=torch.float32, device=dev)
             dist.all_reduce(t, group=g)
@@ -551,6 +553,10 @@ def main():
             return ctx.fst_reduce_pairs_dev(cols[0], cols[1], cols[2], wtab, out=out, tree=tree_)
         return ctx.fst_reduce_dev(cols[0], cols[1][0], cols[2][0], wtab, out=out, tree=tree_)
 
+    # about PREWARM_S seconds of steps, from the largest shard's size (identical on every rank)
+    max_resident = max(int(s_["site_hi"] - s_["site_lo"]) for s_ in shards)
+    prewarm_steps = int(min(500, max(20, PREWARM_S / (max_resident * BYTES_PER_SITE * n_tables / 6.5e12 + 30e-6))))
+
     def timed_region(ex):
         def step():
             out = ex.begin()
@@ -563,6 +569,13 @@ def main():
                 dist.barrier(group=group)
             torch.cuda.synchronize()
 
+        # bring the GPU to its steady state first: after the set-up phase (host-side table building, allocation) the first legs of a
+        # process have read up to 3.5 % slower than the same steps two seconds later (profiles/r04/README.md); about PREWARM_S
+        # seconds of untimed steps, then the W warm-up steps the caller asked for, then exactly K timed steps
+        for k in range(prewarm_steps):  # the same count on every rank: every step issues its collective
+            step()
+            if k % 10 == 9:
+                ex.flush()
         for _ in range(args.warmup):
             step()
         fence()
@@ -695,6 +708,7 @@ def main():
                                            "site ranges sharded over the GPUs"),
                        "sites_total": n_total, "sites_resident_per_gpu": per_gpu, "winsize": W, "stepsize": S,
                        "windows": int(win.size), "seed": SEED, "row_exchange": head_mode, "collective_backend": backend_desc,
+                       "prewarm_steps": prewarm_steps,
                        "parallelism": f"site-range shards x{world}" if world > 1 else "single GPU"},
             "rows_sha256": sha,
             "rows_check": rows_check,

@@ -124,3 +124,21 @@ def test_bench_second_transport_that_never_returns_degrades_to_the_gather_line()
     assert two["extra"]["exchange_peer"]["available"] is False and "deadline" in two["extra"]["exchange_peer"]["why"]
     assert "second transport abandoned" in two["extra"]["note"]
     assert "degrading to the result secured before it" in r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_falls_back_to_cpu_staged_rows_when_rccl_cannot_be_brought_up():
+    """Two ranks on ONE GPU without the rehearsal backend knob: RCCL refuses (or never finishes) a communicator with two
+    ranks on the same device, so this is the real thing the fallback exists for — the probe all-reduce fails or overruns its
+    60 s on the helper thread, the ranks agree over the gloo control group, the rows are staged through the CPU, the line
+    says so, the table is still the single-GPU table bit for bit."""
+    env = _rehearsal_env()
+    env.pop("PGT_BENCH_BACKEND")
+    one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
+                               env=env, timeout=400))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env,
+                       timeout=600)
+    two = _line(r)
+    assert two["ok"] is True and two["rows_sha256"] == one["rows_sha256"] and two["rows_check"].startswith("bitwise equal")
+    assert "FALLBACK" in two["config"]["collective_backend"], two["config"]["collective_backend"]
+    assert "RCCL unusable" in r.stderr

@@ -101,6 +101,8 @@ def main():
     print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A, {BURST} call(s) per measurement\n")
     print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms | step B - A paired |")
     print("|---|---|---|---|---|---|---|---|---|")
+    if os.environ.get("AB_ONLY"):  # e.g. AB_ONLY=AF: only the configurations whose name contains the string
+        configs = [c for c in configs if os.environ["AB_ONLY"] in c[0]]
     emax = int((ewin_h["hi"] - ewin_h["lo"]).max())
     for name, bps, fn in configs:
         for c in (ctx_a, ctx_b):
