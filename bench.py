@@ -58,6 +58,9 @@ import tempfile
 import time
 
 
+PREWARM_S = 0.5  # about this many seconds of untimed steps before the warm-up steps of every timed region (config.prewarm_steps)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sites", type=float, default=5e7,
                     help="sample size of the CPU baseline leg (5e7 sites = 1.6 GB of text, ~10 s of the reference tool)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=PREWARM_S,
+                    help="about this many seconds of untimed steps before the warm-up steps of every timed region (0: none, e.g. under "
+                         "rocprofv3 --pmc, where every dispatch is serialised)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
@@ -204,6 +210,10 @@ if __name__ == "__main__":
         sys.exit(self_launch(_args))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL, hipIpc)
+# one node: the rendezvous (127.0.0.1), gloo's pairs and RCCL's bootstrap all go over loopback — no dependence on the
+# container's hostname resolving or on which interface a library would pick by itself
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -218,7 +228,6 @@ from popgenomicstools_amd.distributed import RowExchange  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
 
-PREWARM_S = 0.5      # about this many seconds of untimed steps before the warm-up steps of every timed region (config.prewarm_steps)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
 BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
 SEED = 12345
@@ -555,7 +564,8 @@ def main():
 
     # about PREWARM_S seconds of steps, from the largest shard's size (identical on every rank)
     max_resident = max(int(s_["site_hi"] - s_["site_lo"]) for s_ in shards)
-    prewarm_steps = int(min(500, max(20, PREWARM_S / (max_resident * BYTES_PER_SITE * n_tables / 6.5e12 + 30e-6))))
+    prewarm_steps = int(min(500, max(20, args.prewarm_seconds / (max_resident * BYTES_PER_SITE * n_tables / 6.5e12 + 30e-6)))) \
+        if args.prewarm_seconds > 0 else 0
 
     def timed_region(ex):
         def step():

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Randomised differential fuzzer of the device-side ingest at CLI level: random fst / het / MAF files (random
+"""Randomised differential fuzzer of the device-side ingest at CLI level: random fst / het / MAF / selscan *.norm files (random
 separators, number formats, CRLF, blank-line stops, missing newline at the end, a bad line now and then) through
 the hosts with PGT_GPU_INGEST=1 and =0 — once more with two or three contexts (PGT_DEVICES=0,0[,0]: the multi-GPU paths, both
-parsers), and in passes (PGT_MAX_RESIDENT_SITES): stdout, stderr and exit code must be identical.
+parsers), and in passes (PGT_MAX_RESIDENT_SITES): stdout, stderr and exit code must be identical.  ihsWindow / xpehhWindow (round 4):
+well-formed files additionally against the unmodified reference binaries (oracle/_ref/), the refusal beyond the resident limit.
 usage: python tests/ingest_fuzz.py [seconds] [seed]"""
 import os
 import subprocess
@@ -43,6 +44,9 @@ def make_file(rng, path, kind):
     lines = []
     if kind == "maf":
         lines.append("chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd")
+    if kind == "xpehh":
+        lines.append("id\tpos\tgpos\tp1\tihh1\tp2\tihh2\txpehh\tnormxpehh\tcrit")
+    id_style = int(rng.integers(0, 3))  # selscan locus ids: chr_pos, chr_pos_tag, or (now and then) an id without '_
     for i in range(n):
         if i == blank_at:
             lines.append(" " if rng.random() < 0.5 else "")
@@ -50,6 +54,13 @@ def make_file(rng, path, kind):
             toks = ["c%d" % chrs[i], str(pos[i]), fmt_float(rng, rng.normal(0, 0.05)), fmt_float(rng, rng.random() * 0.3)]
         elif kind == "het":
             toks = ["c%d" % chrs[i], str(pos[i]), str(int(rng.choice([0, 1, 2, -1, 3, -9])))]
+        elif kind in ("ihs", "xpehh"):  # <chr>_<id> pos f0 .. ; the score is numeric field 4 (iHS) / 6 (XP-EHH) behind the position
+            lid = "c%d" % chrs[i] if id_style == 2 else ("c%d_%d" % (chrs[i], pos[i]) if id_style == 0 else "c%d_%d_x%d" % (chrs[i], pos[i], i % 7))
+            score = float(np.round(rng.normal(0, 1.3), 4)) if rng.random() < 0.97 else 2.5  # ties now and then
+            nf = 6 if kind == "ihs" else 8
+            fields = [fmt_float(rng, rng.random()) for _ in range(nf)]
+            fields[4 if kind == "ihs" else 6] = fmt_float(rng, score)
+            toks = [lid, str(pos[i])] + fields
         else:
             toks = ["c%d" % chrs[i], str(pos[i]), "A", "C", "A", fmt_float(rng, rng.random()), str(int(rng.integers(0, 21)))]
         if i == bad_at:
@@ -61,6 +72,7 @@ def make_file(rng, path, kind):
     text = eol.join(lines) + (eol if rng.random() < 0.85 else "")
     with open(path, "w", newline="") as f:
         f.write(text)
+    make_file.well_formed = bad_at < 0 and blank_at < 0 and eol == "\n" and text.endswith("\n")
     return n
 
 
@@ -86,13 +98,15 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     d = tempfile.mkdtemp(prefix="pgt_ingest_fuzz_")
     t0, trials, last = time.time(), 0, time.time()
-    counts = {"fst": 0, "het": 0, "maf": 0, "errors": 0}
+    counts = {"fst": 0, "het": 0, "maf": 0, "ihs": 0, "xpehh": 0, "errors": 0}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_bind  # the compiled reference binaries (oracle/_ref/, where they travelled): the live check of the extreme-score hosts
     while time.time() - t0 < budget:
         trials += 1
         if time.time() - last > 30:
             print(f"  ... {trials} trials, {time.time() - t0:.0f} s", flush=True)
             last = time.time()
-        kind = ["fst", "het", "maf"][int(rng.integers(0, 3))]
+        kind = ["fst", "het", "maf", "ihs", "xpehh"][int(rng.integers(0, 5))]
         W = int(rng.integers(1, 400))
         S = int(rng.integers(1, W + 1))
         if kind == "maf":
@@ -119,6 +133,21 @@ def main():
                 Wb = int(rng.choice([W * 30, W * 3000]))
                 opts += ["-winsize", str(Wb), "-stepsize", str(max(1, Wb // int(rng.integers(1, 6)))), "-sizefile", fs]
             cmd = [os.path.join(BIN, "dxyWindow")] + opts + [f1, f2]
+        elif kind in ("ihs", "xpehh"):
+            f = os.path.join(d, kind + ".norm")
+            make_file(rng, f, kind)
+            Wb, cutoff = int(rng.choice([W * 30, W * 3000])), "%.2f" % (rng.random() * 3)
+            cmd = ([os.path.join(BIN, "ihsWindow"), f, "-winsize", str(Wb), "-cutoff", cutoff] if kind == "ihs" else
+                   [os.path.join(BIN, "xpehhWindow"), f, cutoff, "-winsize", str(Wb)])
+            ref = oracle_bind.ref_binary(kind + "Window")
+            if ref and make_file.well_formed:  # the unmodified reference on the same file: byte-identical stdout
+                r0 = subprocess.run([ref] + cmd[1:], capture_output=True, timeout=120)
+                h0 = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_GPU_INGEST="1"), timeout=120)
+                if r0.returncode == 0 and (h0.returncode, h0.stdout) != (0, r0.stdout):
+                    print("MISMATCH against the reference binary", cmd, h0.returncode, h0.stderr[-200:], "files kept in", d)
+                    keep_failure(d, cmd, {"reference": r0, "host_device_parser": h0})
+                    sys.exit(1)
+                counts["vs_reference"] = counts.get("vs_reference", 0) + 1
         else:
             f = os.path.join(d, kind + ".txt")
             make_file(rng, f, kind)
@@ -146,7 +175,12 @@ def main():
                 keep_failure(d, cmd, {"single": a, "hybrid": c})
                 sys.exit(1)
             counts["hybrid"] = counts.get("hybrid", 0) + 1
-        if True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
+        if kind in ("ihs", "xpehh"):  # no passes mode: an input beyond the limit is refused, nothing printed
+            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_MAX_RESIDENT_SITES="70000"), timeout=120)
+            if not (c.returncode == 255 and c.stdout == b"" and b"no passes mode" in c.stderr):
+                print("MISMATCH (refusal beyond the resident limit)", cmd, c.returncode, c.stderr[-200:], "files kept in", d)
+                sys.exit(1)
+        elif True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
             limit = int(rng.choice([1, 70000, 150000]))
             env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))
             if rng.random() < 0.5:

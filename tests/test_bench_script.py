@@ -142,3 +142,35 @@ def test_bench_falls_back_to_cpu_staged_rows_when_rccl_cannot_be_brought_up():
     assert two["ok"] is True and two["rows_sha256"] == one["rows_sha256"] and two["rows_check"].startswith("bitwise equal")
     assert "FALLBACK" in two["config"]["collective_backend"], two["config"]["collective_backend"]
     assert "RCCL unusable" in r.stderr
+
+
+@pytest.mark.timeout(600)
+def test_rccl_probe_brings_up_a_communicator_beside_the_gloo_control_group():
+    """bench.bring_up_collectives as the ranks of an N > 1 run call it — gloo default group, RCCL as a second group created
+    and probed on a helper thread — with the one rank a 1-GPU box allows: the API sequence (new_group(backend="nccl",
+    device_id=...) on top of a gloo default group, all-reduce, agreement over gloo) is what the 8-GPU run executes."""
+    code = """
+import os, sys, json
+sys.argv = ['bench.py']
+import torch, bench
+import torch.distributed as dist
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+ph = bench.Phases(0, 1)
+with ph('init'):
+    group, coll_dev, desc = bench.bring_up_collectives(1, 0, dev, ph)
+t = torch.full((4,), 3.0, device=coll_dev)
+dist.all_reduce(t, group=group)
+w = dist.barrier(group=group)
+out = [torch.zeros(8, dtype=torch.uint8, device=coll_dev)]
+dist.gather(torch.arange(8, dtype=torch.uint8, device=coll_dev), out, dst=0, group=group)
+print(json.dumps({'desc': desc, 'dev': str(coll_dev), 'sum': float(t.sum().item()), 'gathered': out[0].cpu().tolist()}), flush=True)
+os._exit(0)
+"""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    env.pop("PGT_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert got["desc"] == "nccl (RCCL)" and got["dev"] == "cuda:0" and got["sum"] == 12.0 and got["gathered"] == list(range(8)), (got, r.stderr[-1500:])

@@ -18,10 +18,10 @@ python bench.py > "$OUT/bench_default.log" 2>&1; echo "bench default rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o bench -- python3 bench.py --steps 20 --warmup 3 --headline-only > "$OUT/bench_under_rocprofv3.log" 2>&1; echo "rocprof stats rc=$?"
 python tools/trim_rocprof.py stats "$(find "$OUT/prof_stats" -name '*kernel_stats.csv' | head -1)" > "$OUT/bench_1e9_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o $c -- python3 bench.py --steps 3 --warmup 1 --no-cpu --headline-only > "$OUT/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/prof_pmc" -o $c -- python3 bench.py --steps 3 --warmup 1 --no-cpu --headline-only --prewarm-seconds 0 > "$OUT/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
 done
 python tools/trim_rocprof.py pmc "$(dirname "$(find "$OUT/prof_pmc" -name '*counter_collection.csv' | head -1)")" > "$OUT/pmc_counters.csv" 2>/dev/null || python tools/trim_rocprof.py pmc "$OUT/prof_pmc" > "$OUT/pmc_counters.csv"
-python tools/trim_rocprof.py headline "$OUT/pmc_counters.csv" "$R" "bench.py --steps 3 --warmup 1 --no-cpu --headline-only" > "$OUT/pmc_headline.json"; echo "pmc headline rc=$?"
+python tools/trim_rocprof.py headline "$OUT/pmc_counters.csv" "$R" "bench.py --steps 3 --warmup 1 --no-cpu --headline-only --prewarm-seconds 0" > "$OUT/pmc_headline.json"; echo "pmc headline rc=$?"
 for n in 1e8 1e9; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k$n" -o k -- python3 tools/pmc_kernels.py $n > "$OUT/kernels_$n.log" 2>&1; echo "kernels $n rc=$?"
   python tools/trim_rocprof.py stats "$(find "$OUT/prof_k$n" -name '*kernel_stats.csv' | head -1)" > "$OUT/kernels_${n}_kernel_stats.csv"
