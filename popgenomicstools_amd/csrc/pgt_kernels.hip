@@ -107,6 +107,13 @@ struct TreeView {
 // is (i) at least two consecutive batches from the same stream — phases of 16 leaves do as well as 64, phases of one
 // 8-load batch are back at the old rate — and (ii) a SHORT queue: 4 loads in flight beat 8 beat 16 (83.8 / 82.0 / 80.4 at
 // 10^9 sites on one box), 2 and 1 are latency-bound (65 / 40 %); more waves per CU with a shallower stage lose (77 %).
+// THE TILE SCHEDULE STAYS STATIC (round 4).  Handing the tiles out by an atomic ticket counter after a static first round
+// (self-resetting counter, one per pair and stream; rows bit-identical) was measured on the fst, dxy, fused and extreme-score
+// builds: -12 ... -23 % at 1e8-1.25e8 sites, -1 ... -3 % at 1e9, with the ticket drawn at the tile's end or half a tile ahead:
+// a fixed ~50 us per launch, because the first round ends in lockstep and ~2000 waves reach the one counter together — and
+// again with their failing draws at the end (one word takes ~88 draws per microsecond).  Other geometries (4 / 16 / 32 waves
+// per CU, 8 / 16 loads in flight) and a deeper queue in a wave's last tile (TAIL_* below) are within +-2 % or win at one size
+// and lose at the next.  profiles/HISTORY.md A1-A2, profiles/r04/README.md.
 constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
@@ -165,7 +172,7 @@ __device__ __forceinline__ void fst_column_sums(const double2 *__restrict__ p, i
 // UNROLL: loads in flight per lane (one column at a time).  TAIL_UNROLL / TAIL_SCOPE (tuning): the queue depth of a wave's LAST
 // tile (scope 2: both columns, 1: only `b`, 0: off) — during the last round ever fewer waves are left to keep the HBM busy.
 template <int STAGE = kFstStage, int UNROLL = 4, bool NT_STORE = true, int TAIL_UNROLL = UNROLL, int TAIL_SCOPE = 0>
-__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv, uint64_t t_begin = 0) {
+__global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t n, uint64_t n_l2, TreeView tv) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
     NodeStage<NodeFst, STAGE, NT_STORE> stage(lds_stage, wib, lane, l1, l2, n_waves);
 
-    for (uint64_t t = t_begin + wave0; t < n_l2; t += n_waves) {  // n_l2 is the end of this launch's tile range
+    for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
         double keep_a = 0.0, keep_b = 0.0;
         if (base + kTile2 <= n) {
@@ -1588,7 +1595,7 @@ int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function
 namespace {
 void fst_build_launch(hipStream_t s, const PairCols &cols, uint32_t np, uint64_t n, const TreeLayout &tl, const TreeView &tv) {
     const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks), np);
-    hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv, (uint64_t)0);
+    hipLaunchKernelGGL((fst_build_kernel<>), grid, dim3(256), kFstStageBytes, s, cols, n, tl.count[1], tv);
 }
 
 // launch_fst with the build launch as a parameter: the product passes fst_build_launch; tools/pgt_kernels_tuning.hip

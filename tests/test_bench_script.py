@@ -99,15 +99,15 @@ def test_bench_rank_lost_or_wedged_mid_run_fails_fast_and_names_the_phase():
     # (b) rank 1 wedges in the timed gather: BOTH ranks' watchdogs name the phase (rank 0 waits in the collective)
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:gather timed:hang",
-                                                                                PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
+                                                                                PGT_BENCH_DEADLINE_SCALE="0.15"), timeout=400)
     took = time.time() - t0
     assert r.returncode != 0 and took < 200, took
-    assert "phase 'gather timed' exceeded its deadline of 15 s" in r.stderr, r.stderr[-3000:]
+    assert "phase 'gather timed' exceeded its deadline of 9 s" in r.stderr, r.stderr[-3000:]
     assert "[bench r1/2" in r.stderr and "giving up (exit 124)" in r.stderr
     # (c) rank 0 wedges while rebuilding the genome for the check
     r = subprocess.run(cmd, capture_output=True, text=True, env=_rehearsal_env(PGT_BENCH_FAULT="0:verify:hang",
-                                                                                PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
-    assert r.returncode != 0 and "phase 'verify' exceeded its deadline of 30 s" in r.stderr, r.stderr[-3000:]
+                                                                                PGT_BENCH_DEADLINE_SCALE="0.15"), timeout=400)
+    assert r.returncode != 0 and "phase 'verify' exceeded its deadline of 18 s" in r.stderr, r.stderr[-3000:]
 
 
 @pytest.mark.timeout(600)
@@ -117,7 +117,7 @@ def test_bench_second_transport_that_never_returns_degrades_to_the_gather_line()
     one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True,
                                env=_rehearsal_env(), timeout=400))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "both"] + SMALL, capture_output=True,
-                       text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:peer timed:hang", PGT_BENCH_DEADLINE_SCALE="0.25"), timeout=400)
+                       text=True, env=_rehearsal_env(PGT_BENCH_FAULT="1:peer timed:hang", PGT_BENCH_DEADLINE_SCALE="0.15"), timeout=400)
     two = _line(r)
     assert two["config"]["row_exchange"] == "gather" and two["rows_sha256"] == one["rows_sha256"] and two["ok"] is True
     assert two["extra"]["exchange_gather"]["rows_check"] == "bitwise equal" and two["extra"]["exchange_gather"]["headline"]
