@@ -212,8 +212,9 @@ if __name__ == "__main__":
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL, hipIpc)
 # one node: the rendezvous (127.0.0.1), gloo's pairs and RCCL's bootstrap all go over loopback — no dependence on the
 # container's hostname resolving or on which interface a library would pick by itself
-os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+if os.path.isdir("/sys/class/net/lo"):
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
