@@ -234,11 +234,13 @@ BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
 SEED = 12345
 
 
-def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None):
+def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside=None):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload:
     the first n_sample sites written as the tool's text input, then the UNMODIFIED reference binary
     (oracle/_ref/fstWindow, kind "reference") — or, if that binary did not travel, our restatement
-    (oracle/liboracle.so, kind "port") — timed end to end, single-threaded like the reference."""
+    (oracle/liboracle.so, kind "port") — timed end to end, single-threaded like the reference.
+    beside: callable(done) run on the calling thread WHILE the CPU run goes on a worker thread (its clock is taken there):
+    the sustained leg, which keeps the GPU busy for those ~12 s (one of this box's 256 cores launches kernels meanwhile)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind
     orc = oracle_bind.load()
@@ -250,15 +252,30 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None):
     path = os.path.join(tmpdir, "sample.fst.txt")
     orc.write_fst_text(path, chr_ids, hp, ha, hb)
     ref = oracle_bind.ref_binary("fstWindow")
-    t0 = time.perf_counter()
-    if ref:
-        with open(os.devnull, "w") as devnull:
-            subprocess.run([ref, path, str(W), str(S)], stdout=devnull, check=True)
-        kind = "reference"
-    else:
-        assert orc.fst_text(path, W, S, os.devnull) == 0
-        kind = "port"
-    dt = time.perf_counter() - t0
+    kind = "reference" if ref else "port"
+    timing = {}
+
+    def cpu_run():
+        t0 = time.perf_counter()
+        try:
+            if ref:
+                with open(os.devnull, "w") as devnull:
+                    subprocess.run([ref, path, str(W), str(S)], stdout=devnull, check=True)
+            else:
+                assert orc.fst_text(path, W, S, os.devnull) == 0  # a ctypes call: the GIL is released while it runs
+            timing["dt"] = time.perf_counter() - t0
+        except BaseException as e:  # noqa: BLE001 — reported on the calling thread
+            timing["error"] = e
+
+    import threading
+    th = threading.Thread(target=cpu_run)
+    th.start()
+    if beside is not None:
+        beside(lambda: not th.is_alive())
+    th.join()
+    if "error" in timing:
+        raise timing["error"]
+    dt = timing["dt"]
     if ctx is not None and extra is not None:
         # the same text through the device-side ingest (pgt_ingest_text): the parsed columns must equal the resident ones
         from popgenomicstools_amd._lib import PGT_TOK_CHR, PGT_TOK_F64, PGT_TOK_U32
@@ -310,10 +327,11 @@ def timed_config(ctx, call, alg_bytes, reps=15):
             "roofline_frac": alg_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def sustained_leg(step, alg_bytes_per_step, sites, seconds=2.5, chunks=10):
-    """>= `seconds` of back-to-back headline steps, WALL-timed (perf_counter between two device synchronisations), so that
-    an outside sampler (rocm-smi, the driver's) sees the GPU busy and a clock droop under sustained load would show: the
-    rate of each tenth of the run is reported beside the whole (HIP events between the chunks)."""
+def sustained_leg(step, alg_bytes_per_step, sites, seconds=2.5, until=None, max_seconds=60.0, chunk_seconds=0.25):
+    """>= `seconds` of back-to-back headline steps — and, with `until`, on until that callable says stop (the CPU baseline runs
+    beside this leg: ~12 s) — WALL-timed between two device synchronisations, so that an outside sampler (rocm-smi, the driver's)
+    sees the GPU busy and a clock droop under sustained load would show: the rate of every quarter second is reported beside the
+    whole (HIP events between the chunks)."""
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -322,23 +340,32 @@ def sustained_leg(step, alg_bytes_per_step, sites, seconds=2.5, chunks=10):
         step()
     torch.cuda.synchronize()
     per = (time.perf_counter() - t0) / 10
-    per_chunk = max(1, int(np.ceil(seconds / per / chunks)))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    per_chunk = max(1, int(np.ceil(chunk_seconds / per)))
+    marks = [torch.cuda.Event(enable_timing=True)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
-    for c in range(chunks):
+    while True:
         for _ in range(per_chunk):
             step()
-        marks[c + 1].record()
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[-1].record()
+        marks[-1].synchronize()  # at most one chunk is queued ahead: the loop ends within a chunk of `until`
+        el = time.perf_counter() - t0
+        if el >= max_seconds or (el >= seconds and (until is None or until())):
+            break
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    chunks = len(marks) - 1
     steps = per_chunk * chunks
     chunk_gbs = [alg_bytes_per_step * per_chunk / (marks[c].elapsed_time(marks[c + 1]) * 1e-3) / 1e9 for c in range(chunks)]
-    return {"config": f"{steps} back-to-back steps of the headline workload, wall-clocked between two device synchronisations",
+    return {"config": f"{steps} back-to-back steps of the headline workload, wall-clocked between two device synchronisations"
+                      + (" — running beside the CPU baseline, for as long as that took" if until is not None else ""),
             "steps": steps, "wall_seconds": wall, "ms_per_step": wall / steps * 1e3, "sites_per_s": sites * steps / wall,
             "GB_per_s": alg_bytes_per_step * steps / wall / 1e9, "frac_of_hbm_peak": alg_bytes_per_step * steps / wall / 1e9 / HBM_PEAK_GBS,
-            "chunk_GB_per_s": [round(x, 1) for x in chunk_gbs],
+            "chunks": chunks, "steps_per_chunk": per_chunk,
+            "chunk_GB_per_s_min_median_max": [round(float(np.min(chunk_gbs)), 1), round(float(np.median(chunk_gbs)), 1), round(float(np.max(chunk_gbs)), 1)],
+            "chunk_GB_per_s_first_10": [round(x, 1) for x in chunk_gbs[:10]], "chunk_GB_per_s_last_10": [round(x, 1) for x in chunk_gbs[-10:]],
             "first_vs_last_chunk": chunk_gbs[-1] / chunk_gbs[0]}
 
 
@@ -777,13 +804,18 @@ def main():
                 extra = extra_configs(ctx, dev, W, S, tree)
                 ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
                 ctx.set_window_step(S)
+        sust_out = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
+
+        def sustained(until=None):
+            extra["sustained"] = sustained_leg(lambda: scan(mycols, win_d, sust_out, tree), BYTES_PER_SITE * n, n, until=until)
+
+        if args.no_cpu and not args.headline_only:
             with ph("sustained"):
-                sust_out = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
-                extra["sustained"] = sustained_leg(lambda: scan(mycols, win_d, sust_out, tree), BYTES_PER_SITE * n, n)
-                del sust_out
+                sustained()
         if not args.no_cpu:
-            with ph("cpu baseline"):
-                cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra)
+            with ph("cpu baseline"):  # with the sustained leg beside it (not in --headline-only runs: rocprofv3 traces every dispatch)
+                cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra, beside=None if args.headline_only else sustained)
+        del sust_out
 
     if rank == 0:
         print(assemble(runs, build_avg, query_avg, extra, cpu), flush=True)
