@@ -225,7 +225,11 @@ int orc_dxy_scan(const uint32_t *chr, const uint32_t *pos, const double *p1, con
     if (W > 0 && check_ws(W, S)) return ORC_EARG; /* dxyWindow.cpp:128-131 + Q9 */
     if (W == 0 && !fixedsite) return ORC_EDOMAIN; /* Q10: the reference indexes an empty vector */
     if (!fixedsite && !run_chr_len) return ORC_EARG;
-    if (n == 0) return ORC_EDOMAIN; /* the reference reads a first site unconditionally (:285-292) */
+    /* no site at all: the reference reads a first site of both files unconditionally (:285-292) — undefined on an empty
+     * file.  With n_runs >= 1 the caller says "both files had data lines but the synchronisation of :315-331 matched none
+     * of them" (orc_dxy_text): the main loop then breaks at its first pass and only the code behind it runs — the padding of
+     * the first line's chromosome (:407-421), the last flush (:424) and the all-zero genome-wide line (:429-433). */
+    if (n == 0 && n_runs == 0) return ORC_EDOMAIN;
     wbuf wb;
     if (wbuf_init(&wb, W, S)) return ORC_EIO;
     sink sk = {out, cap, 0};
@@ -511,6 +515,10 @@ int orc_dxy_text(const char *maf1, const char *maf2, const char *sizefile, uint3
             if (j + 1 >= t2.n) break; /* :402 */
             ++j;
         }
+        /* nothing matched (the first pass of the loop broke at :323 / :330): `chr` still names the first line's chromosome
+         * (:293) and the code behind the loop pads it — one run without sites (found by tests/dxy_stream_model.py, round 4:
+         * this restatement used to refuse such a pair) */
+        if (m.n == 0 && table_run(&m, t1.run_name[t1.chr[0]], strlen(t1.run_name[t1.chr[0]]))) { rc = ORC_EIO; goto done; }
     }
 
     uint64_t slots = 0;

@@ -175,4 +175,6 @@ def hand_walked_product_expectation(case, run):
     documented deliberate divergences — the output of the machine on the sites both files list."""
     if case["product"] == "same":
         return run["stdout"], run["stderr"]
+    if case["product"].get("rc", 0) != 0:  # the product refuses this input (exit status, a phrase of the message); nothing on stdout
+        return None, case["product"]["stderr_contains"]
     return case["product"]["stdout"], case["product"]["stderr"]

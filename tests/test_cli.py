@@ -203,6 +203,9 @@ def test_dxy_cli_hand_walked_cases(hosts, tmp_path, env_extra):
             if not r["fixedsite"]:
                 cmd += ["-sizefile", sz]
             got = run(cmd + [m1, m2], env=dict(os.environ, **env_extra))
+            if want_out is None:  # refused (H10: no shared site)
+                assert got.returncode == 255 and got.stdout == "" and want_err in got.stderr, (c["name"], got.returncode, got.stderr)
+                continue
             assert got.returncode == 0, (c["name"], got.stderr)
             assert got.stdout == want_out, (c["name"], r, env_extra, got.stdout)
             assert got.stderr == want_err, (c["name"], r, env_extra, got.stderr)

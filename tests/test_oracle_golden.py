@@ -110,7 +110,7 @@ def test_dxy_hand_walked_cases(oracle, tmp_path):
     literally, so it must print the walked output byte for byte — INCLUDING where the reference's behaviour is a quirk
     the product does not follow.  An independent derivation, not a reference-made pin (the grade stays 'unpinned')."""
     k = helpers.load_golden("dxy_hand_walked.json")
-    assert len(k["cases"]) >= 9 and all(len(c["walk"]) >= 3 for c in k["cases"])
+    assert len(k["cases"]) >= 10 and all(len(c["walk"]) >= 3 for c in k["cases"])
     n = 0
     for c in k["cases"]:
         m1, m2, sz = helpers.write_hand_walked_case(c, k["header"], tmp_path)
@@ -122,7 +122,7 @@ def test_dxy_hand_walked_cases(oracle, tmp_path):
             assert o.read_text() == r["stdout"], (c["name"], r, o.read_text())
             assert e.read_text() == r["stderr"], (c["name"], r, e.read_text())
             n += 1
-    assert n >= 11
+    assert n >= 14
 
 
 def test_dxy_reference_made_cases(oracle, tmp_path):
@@ -345,3 +345,75 @@ def test_wcfst_restatement_against_exact_rational_evaluation(oracle):
         assert np.all(np.abs(a - ea) <= 1e-12 * scale + 1e-15), (c["n1"], c["n2"], a - ea)
         assert abs(a.sum() / ab.sum() - c["genome_fst_f64"]) <= 1e-12
         assert float(Fraction(c["sum_a"]) / Fraction(c["sum_a_plus_b"])) == c["genome_fst_f64"]
+
+
+def test_dxy_oracle_against_the_independent_stream_model(oracle, tmp_path):
+    """The C oracle's dxyWindow restatement against tests/dxy_stream_model.py — the same reference lines
+    (dxyWindow.cpp:172-209, 282-433) restated a second time, in Python, as the reference runs them (line readers that run
+    dry, the catch-up loops, slot padding, calcWindow's static) — on 1 500 random file pairs: identical site lists, pop2
+    within pop1, pop1 within pop2 and NON-nested lists (where the reference's behaviour is a quirk, but a defined one:
+    both restatements must reproduce it), 1-4 chromosomes, both window modes, -winsize 0, -skip_missing, chromosomes
+    missing from the size file.  stdout, stderr and the exit status byte for byte.  Pins nothing (the reference cannot be
+    built here); it removes transcription slips that one restatement alone could hide."""
+    import random
+
+    import dxy_stream_model as model
+    rng = random.Random(20261004)
+    hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd"
+    kinds = {"same": 0, "pop2_in_pop1": 0, "pop1_in_pop2": 0, "other": 0}
+    n_rows = errors = 0
+    for trial in range(1500):
+        n_chr = rng.randint(1, 4)
+        rows1, rows2, sizes = [], [], {}
+        kind = rng.choice(list(kinds))
+        for c in range(n_chr):
+            L = rng.randint(1, 30)
+            sites = sorted(rng.sample(range(1, L + 1), rng.randint(1, min(L, 8))))
+            name = f"c{c}"
+            if rng.random() < 0.95:
+                sizes[name] = L + (rng.randint(0, 3) if rng.random() < 0.3 else 0) - (1 if rng.random() < 0.05 and L > 1 else 0)
+            for p in sites:
+                in1 = kind in ("same", "pop2_in_pop1") or rng.random() < 0.7
+                in2 = kind in ("same", "pop1_in_pop2") or rng.random() < 0.7
+                if in1:
+                    rows1.append((name, p, round(rng.random(), 6), rng.randint(0, 6)))
+                if in2:
+                    rows2.append((name, p, round(rng.random(), 6), rng.randint(0, 6)))
+        if not rows1 or not rows2:
+            continue
+        kinds[kind] += 1
+        mode = rng.randint(0, 3)
+        W = rng.randint(1, 9)
+        S = rng.randint(1, W)
+        if mode == 0:
+            W, S, fixed = 0, 0, 1
+        else:
+            fixed = 1 if mode == 1 else 0
+        minind, skip = rng.randint(1, 4), rng.randint(0, 1)
+        f1, f2, fs = tmp_path / "p1.mafs", tmp_path / "p2.mafs", tmp_path / "sizes.txt"
+        _write_maf(f1, hdr, rows1)
+        _write_maf(f2, hdr, rows2)
+        fs.write_text("".join(f"{c}\t{n}\n" for c, n in sizes.items()))
+        o, e = tmp_path / "o.txt", tmp_path / "e.txt"
+        rc = oracle.dxy_text(str(f1), str(f2), None if fixed else str(fs), W, S, minind, fixed, skip, str(o), str(e))
+        mrc, mout, merr = model.maf2dxy(rows1, rows2, W, S, minind, fixed, sizes, skip)
+        if mrc != 0:  # "Chromosomes in MAF files differ" / "Unable to determine size for X": the reference exits 255 (after some
+            assert rc != 0, (trial, kind, mode)  # rows, in the second case); the oracle reports a status, no text
+            errors += 1
+            continue
+        assert rc == 0, (trial, kind, mode, e.read_text())
+        assert o.read_text() == mout, (trial, kind, mode, W, S, rows1, rows2, sizes, o.read_text(), mout)
+        assert e.read_text() == merr, (trial, kind, mode, e.read_text(), merr)
+        n_rows += mout.count("\n")
+    assert min(kinds.values()) > 200 and n_rows > 6000 and 50 < errors < 400, (kinds, n_rows, errors)
+
+
+def test_stream_model_reproduces_the_hand_walked_cases():
+    """tests/dxy_stream_model.py on tests/golden/dxy_hand_walked.json: the paper walks and the Python restatement agree."""
+    import dxy_stream_model as model
+    k = helpers.load_golden("dxy_hand_walked.json")
+    for c in k["cases"]:
+        r1, r2 = [tuple(x) for x in c["pop1"]], [tuple(x) for x in c["pop2"]]
+        for r in c["runs"]:
+            assert model.maf2dxy(r1, r2, r["winsize"], r["stepsize"], c["minind"], r["fixedsite"], dict(c["sizes"] or []),
+                                 r["skip_missing"]) == (0, r["stdout"], r["stderr"]), c["name"]
