@@ -11,6 +11,7 @@
 //   5. cut_at_lines (the multi-GPU text cut): the pieces tile the text and start at line starts; chromosome runs parsed
 //      per piece and stitched with Runs::add are the runs of the whole text;
 //   6. scan_runs_and_marks (first scan of the passes mode): rows, runs, end of the data, the byte marks, the position digests;
+//   6b. ScoreTable / read_chrlen (ihsWindow / xpehhWindow: locus-id prefix, score field, errors with line numbers);
 //   7. HostBuf (huge-page mappings for columns, rows and inflated text): alignment, size, every byte writable;
 //   8. resident_limit_for: which inputs are reduced in passes, and of how many sites.
 #include <dirent.h>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "host_common.h"
+#include "extreme_common.h"
 
 using namespace pgthost;
 
@@ -407,6 +409,47 @@ int main(int argc, char **argv) {
                 for (size_t k = 2; k < dig.size(); ++k) CHECK(dig2[k] == dig[k]);
             }
         }
+        unsetenv("PGT_HOST_THREADS");
+    }
+    {   // 6b. ScoreTable (ihsWindow / xpehhWindow, extreme_common.h): `<chr>_<id> pos f0 ..`, the chromosome is the locus id up to its
+        // first '_' (extractChr, ihsWindow.cpp:80-92), the score numeric field 4 (iHS) or 6 (XP-EHH) behind the position; one chunk
+        // and several; a bad score and a missing field are errors with their line number; read_chrlen keeps the first entry of a name
+        const size_t rows_s = 120000;
+        for (int field : {4, 6}) {
+            std::string norm;
+            std::vector<double> want(rows_s);
+            for (size_t i = 0; i < rows_s; ++i) {
+                char line[200];
+                want[i] = (double)(int64_t)(rng() % 8000000 - 4000000) / 1e6;
+                const size_t c = i * 5 / rows_s + 1;
+                int n = std::snprintf(line, sizeof line, i % 3 ? "chr%zu_%zu\t%zu" : "chr%zu_%zu_x\t%zu", c, i + 1, i + 1);
+                for (int k = 0; k <= field + 1; ++k) n += std::snprintf(line + n, sizeof line - (size_t)n, "\t%.6f", k == field ? want[i] : 0.25 * k);
+                line[n++] = '\n';
+                norm.append(line, (size_t)n);
+            }
+            for (int threads : {1, 5}) {
+                setenv("PGT_HOST_THREADS", std::to_string(threads).c_str(), 1);
+                std::string padded = norm;
+                if (threads > 1) padded.append(std::string((1u << 20) + 7, ' '));
+                ScoreTable tab;
+                tab.score_field = field;
+                Runs runs;
+                const size_t got = parse_table(padded.data(), padded.data() + norm.size(), tab, runs, "check", "mem", 1);
+                CHECK(got == rows_s && runs.name.size() == 5 && runs.name[0] == "chr1" && runs.name[4] == "chr5");
+                for (size_t i = 0; i < rows_s && got == rows_s; i += 499) CHECK(tab.score[i] == want[i] && tab.pos[i] == i + 1);
+            }
+            std::string bad = norm.substr(0, norm.find('\n', norm.size() / 2) + 1) + "chr5_9\t9\t0.1\n";  // too few fields on the last line
+            ScoreTable tab;
+            tab.score_field = field;
+            Runs runs;
+            std::string error;
+            (void)parse_table(bad.data(), bad.data() + bad.size(), tab, runs, "check", "mem", 1, &error);
+            CHECK(!error.empty() && error.find("line ") != std::string::npos);
+        }
+        const std::string dirl = argc > 3 ? argv[3] : "/tmp";
+        put_file(dirl + "/chrlen.txt", "chr1\t100\nchr2 250\nchr1\t999\n\nbroken\nchr3\tx\n");
+        const auto lens = read_chrlen((dirl + "/chrlen.txt").c_str());
+        CHECK(lens.size() == 2 && lens.at("chr1") == 100 && lens.at("chr2") == 250);
         unsetenv("PGT_HOST_THREADS");
     }
     {   // 7. HostBuf: malloc below 8 MiB, a 2-MiB-aligned mapping of whole huge pages from there on; every byte writable; release and re-use
