@@ -37,7 +37,7 @@ watchdog thread per rank).  A phase that overruns ends the rank with exit code 1
 wedged rank reads as "rank 3: phase 'gather timed' exceeded its deadline of 60 s", not as a driver timeout; only the
 peer-store transport (opt-in: --exchange both / peer) is DEGRADABLE: once the gather's line is secured, a peer phase
 that overruns makes rank 0 print that line with exchange_peer marked unavailable and every rank exit 0.  The collectives
-run on RCCL (backend nccl) after a probe all-reduce that is given 60 s on a helper thread; if RCCL cannot be brought up
+run on RCCL (backend nccl) after a probe all-reduce that is given 100 s on a helper thread; if RCCL cannot be brought up
 the ranks agree (over the gloo control group, which always exists) to stage the 4 MB of rows through the CPU instead and
 say so in config.collective_backend.  Budget of `--gpus 8` on the 10^9-site genome: < 180 s in all — imports ~20 s,
 init + probe ~15 s, columns ~5 s, gather timed ~1 s, rank 0's rebuild of the whole 20-GB genome + single-GPU scan ~15 s,
@@ -489,7 +489,7 @@ def pmc_traffic(n, n_tables):
 def bring_up_collectives(world, rank, dev, ph):
     """-> (group for the data-path collectives, device their tensors live on, description).
     The default group is gloo over 127.0.0.1 (the control plane: agreement and verdict flags; it comes up wherever TCP does).
-    RCCL (backend nccl) is a second group, probed with one all-reduce on a helper thread that gets 60 s: if the probe
+    RCCL (backend nccl) is a second group, probed with one all-reduce on a helper thread that gets 100 s: if the probe
     fails or does not return on ANY rank, all ranks agree over gloo to stage the rows through the CPU instead."""
     import threading
     from datetime import timedelta
@@ -513,7 +513,7 @@ def bring_up_collectives(world, rank, dev, ph):
 
     th = threading.Thread(target=probe, daemon=True)
     th.start()
-    th.join(min(60.0, 0.5 * ph.deadline_of("init")))
+    th.join(min(100.0, 0.85 * ph.deadline_of("init")))  # a first RCCL bring-up on an eight-GPU node can take tens of seconds
     ok = 1 if (box.get("sum") == float(world)) else 0
     why = box.get("error") or ("probe all-reduce did not return in time" if th.is_alive() else f"probe all-reduce gave {box.get('sum')}")
     flag = torch.tensor([ok], dtype=torch.int32)

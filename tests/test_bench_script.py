@@ -130,7 +130,7 @@ def test_bench_second_transport_that_never_returns_degrades_to_the_gather_line()
 def test_bench_falls_back_to_cpu_staged_rows_when_rccl_cannot_be_brought_up():
     """Two ranks on ONE GPU without the rehearsal backend knob: RCCL refuses (or never finishes) a communicator with two
     ranks on the same device, so this is the real thing the fallback exists for — the probe all-reduce fails or overruns its
-    60 s on the helper thread, the ranks agree over the gloo control group, the rows are staged through the CPU, the line
+    100 s on the helper thread, the ranks agree over the gloo control group, the rows are staged through the CPU, the line
     says so, the table is still the single-GPU table bit for bit."""
     env = _rehearsal_env()
     env.pop("PGT_BENCH_BACKEND")
