@@ -8,7 +8,8 @@
     AB_LIB=tools/_ab/libpgtwin_tuning.so         load this (prebuilt) tuning library instead of rebuilding the tree's
 
 Environment knobs of the tuning build (tools/pgt_kernels_tuning.hip): PGT_TUNE_FST =
-<stage>:<loads in flight>:<workgroups>[:<tail loads>:<tail scope>] (fst build), PGT_EXT_VARIANT_NOW = 0..10 (extreme-score build)."""
+<stage>:<loads in flight>:<workgroups>[:<tail loads>:<tail scope>] (fst build), PGT_TUNE_FST_PAIR = <loads in flight> (fst build, two
+waves per tile), PGT_EXT_VARIANT_NOW = 0..10 (extreme-score build)."""
 import os
 import sys
 
@@ -25,7 +26,7 @@ if os.environ.get("AB_LIB"):  # a tuning library built beforehand (e.g. tools/_a
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
 
-KNOBS = ("PGT_TUNE_FST", "PGT_EXT_VARIANT_NOW")
+KNOBS = ("PGT_TUNE_FST", "PGT_TUNE_FST_PAIR", "PGT_EXT_VARIANT_NOW")
 sizes = [int(float(x)) for x in sys.argv[1:]] or [100_000_000, 125_000_000, 1_000_000_000]
 spec = os.environ.get("AB_VARIANTS", "last tile with 16 loads in flight:PGT_TUNE_FST=16:4:512:16:2;"
                                       "last b column with 16 loads in flight:PGT_TUNE_FST=16:4:512:16:1")
