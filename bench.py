@@ -17,11 +17,12 @@ command above as a CHILD process on a free port of 127.0.0.1, relays its output 
 N > 1 (one process per GPU): the window table is built once (identical on every rank) and cut by
 pgt_plan_shards into N contiguous blocks; rank r materialises ONLY its own site range [site_lo,
 site_hi) of the genome (counter-based generator keyed on the global site index, halo <= one window)
-and reduces its block.  Rows reach rank 0 by an asynchronous double-buffered RCCL gather, or by peer
-stores over xGMI into rank 0's row buffer (no per-step collective).  With --exchange auto (default) BOTH
-transports are timed and each assembled table is checked; "value" is the gather's (the transport
-north_star names) unless the peer-store run was verified bitwise in this very run AND was faster;
-both timings are in "extra" (exchange_gather / exchange_peer).  STRONG scaling: total work is fixed at
+and reduces its block.  Rows reach rank 0 by an asynchronous double-buffered RCCL gather (--exchange auto, the
+default: the transport north_star names, and the only one an unattended run takes) or by peer stores over xGMI into
+rank 0's row buffer (no per-step collective; opt-in).  With --exchange both, BOTH transports are timed — the peer
+stores after the gather's line has been secured — and each assembled table is checked; "value" is the gather's
+unless the peer-store run was verified bitwise in this very run AND was faster; both timings are in "extra"
+(exchange_gather / exchange_peer).  STRONG scaling: total work is fixed at
 --sites; value = --sites x steps / max-over-ranks time.  After each timed region rank 0 rebuilds the whole
 genome (once), runs the single-GPU scan and demands the assembled multi-GPU table to be bitwise equal
 ("rows_check"); the table's SHA-256 ("rows_sha256") is the same for every N.  --scaling weak instead gives

@@ -42,8 +42,9 @@ def test_bench_single_and_two_rank_tables_agree(workload):
 @pytest.mark.timeout(600)
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` exactly as the driver calls it for N = 1 (no launcher, no WORLD_SIZE): the parent starts
-    the two ranks as a child process group, relays rank 0's line and exits with the child's code.  Default --exchange
-    auto: BOTH transports are timed, each table is checked bit for bit, the headline is one of the verified ones."""
+    the two ranks as a child process group, relays rank 0's line and exits with the child's code.  The default (--exchange
+    auto) is the gather alone and every rank announces every phase; with --exchange both, BOTH transports are timed, each
+    table is checked bit for bit, the headline is one of the verified ones."""
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PGT_BENCH_BACKEND="gloo", PGT_BENCH_SHARE_GPU="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
