@@ -113,7 +113,8 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
                    const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, pgt_dxy_total *tot);
 
 /* ---- reductions, device-resident columns (asynchronous on `stream`) --------------------- */
-/* Every pointer is a DEVICE pointer on ctx's device; f64 columns must be 16-byte aligned.
+/* Every pointer is a DEVICE pointer on ctx's device; the f64, i32 (n1, n2) and i8 columns must be 16-byte
+ * aligned (they are read by 16-byte loads; the i32 columns since round 5 — 8 bytes sufficed before).
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).  `tree` is caller
  * workspace of at least pgt_tree_bytes(stat, n) bytes, 256-byte aligned: it receives the
  * radix-64 range tree and may be reused by later calls.

@@ -319,8 +319,8 @@ int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
     if (n == 0 && n_win == 0 && !tot) return PGT_OK;
     if (!p1 || !p2 || !n1 || !n2 || !tree || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
-    if (!aligned16(p1) || !aligned16(p2) || (reinterpret_cast<uintptr_t>(n1) & 7u) || (reinterpret_cast<uintptr_t>(n2) & 7u))
-        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: f64 columns need 16-byte, i32 columns 8-byte alignment");
+    if (!aligned16(p1) || !aligned16(p2) || !aligned16(n1) || !aligned16(n2))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: the f64 and i32 columns must be 16-byte aligned");
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: at most 2^32-1 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: tree workspace too small or misaligned");
@@ -340,8 +340,8 @@ int pgt_dxy_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, 
     if (!p1 || !p2 || !n1 || !n2 || !g1 || !g2 || !tree || (n_win && (!win || !dxy_out || !het_out1 || !het_out2 || !pos)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: NULL argument");
     if (!aligned16(p1) || !aligned16(p2) || !aligned16(g1) || !aligned16(g2) ||
-        (reinterpret_cast<uintptr_t>(n1) & 7u) || (reinterpret_cast<uintptr_t>(n2) & 7u))
-        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: f64/i8 columns need 16-byte, i32 columns 8-byte alignment");
+        !aligned16(n1) || !aligned16(n2))
+        return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: the f64, i32 and i8 columns must be 16-byte aligned");
     if (n >= (1ull << 32)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: at most 2^32-1 sites per call");
     if (!aligned16(tree) || tree_bytes < pgt_tree_bytes(PGT_STAT_DXY, n) + 2 * pgt_tree_bytes(PGT_STAT_HET, n))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_het_reduce: tree workspace too small or misaligned");

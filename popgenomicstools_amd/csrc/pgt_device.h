@@ -42,30 +42,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += __shfl_xor(v, 32, kWave);
     return v;
 }
-// The same sum with the two cross-row steps done by v_permlane16_swap / v_permlane32_swap (gfx950
-// VALU instructions) instead of ds_bpermute (the LDS crossbar): swapping a register with its own copy
-// leaves {x[l], x[l^mask]} in the two registers of every lane, so their sum is one all-reduce step.
-// Bitwise identical to wave_sum (each step still adds x[l] and x[l^mask]).
-__device__ __forceinline__ double xor_swap_sum_f64(double v, bool rows16) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    if (rows16) {
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-    }
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-}
-__device__ __forceinline__ double wave_sum_permlane(double v) {
-    v += dpp_f64<kDppQuadXor1>(v);
-    v += dpp_f64<kDppQuadXor2>(v);
-    v += dpp_f64<kDppRowHalfMirror>(v);
-    v += dpp_f64<kDppRowMirror>(v);
-    v = xor_swap_sum_f64(v, true);
-    v = xor_swap_sum_f64(v, false);
-    return v;
-}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     v += dpp_u32<kDppQuadXor1>(v);
     v += dpp_u32<kDppQuadXor2>(v);
@@ -103,10 +79,12 @@ __device__ __forceinline__ uint4 load16_nt(const uint4 *p) {
 __device__ __forceinline__ void load_fence(double v) { asm volatile("" ::"v"(v) : "memory"); }
 __device__ __forceinline__ void load_fence(int v) { asm volatile("" ::"v"(v) : "memory"); }
 
-__device__ __forceinline__ int2 load8_nt(const int2 *p) {
-    int2 v;
+__device__ __forceinline__ int4 load16_nt(const int4 *p) {
+    int4 v;
     v.x = __builtin_nontemporal_load(&p->x);
     v.y = __builtin_nontemporal_load(&p->y);
+    v.z = __builtin_nontemporal_load(&p->z);
+    v.w = __builtin_nontemporal_load(&p->w);
     return v;
 }
 

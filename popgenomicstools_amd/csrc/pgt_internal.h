@@ -27,8 +27,12 @@ struct TreeLayout {
     int n_levels = 0;                   // levels 1..n_levels exist
     uint64_t count[kMaxLevels] = {};    // nodes stored per level (level 1 padded to 64 * count[1])
     size_t offset[kMaxLevels] = {};     // byte offset of each level in the workspace
+    size_t partials = 0;                // dxy only: byte offset of the build waves' partial sums (the genome-wide line)
     size_t bytes = 0;
 };
+// The build kernels of the f64 trees run on at most this many waves (512 workgroups of 4: what is resident at once, see
+// build_grid in pgt_kernels.hip); the dxy build leaves one partial sum per wave behind the tree.
+constexpr uint32_t kMaxBuildWaves = 2048;
 
 inline int leaf_sites(int stat) { return stat == PGT_STAT_HET ? kLeafI8 : (stat == PGT_STAT_EXT ? kLeafExt : kLeafF64); }
 inline size_t node_bytes(int stat) { return stat == PGT_STAT_HET ? kNodeHet : 16; }
@@ -60,16 +64,24 @@ inline TreeLayout tree_layout_for(uint64_t leaf, size_t nb, uint64_t n_sites) {
     return t;
 }
 inline TreeLayout tree_layout(int stat, uint64_t n_sites) {
-    return tree_layout_for((uint64_t)leaf_sites(stat), node_bytes(stat), n_sites);
+    TreeLayout t = tree_layout_for((uint64_t)leaf_sites(stat), node_bytes(stat), n_sites);
+    if (stat == PGT_STAT_DXY) {  // + one node per build wave: the genome-wide line is their sum (no upper levels needed for it)
+        t.partials = t.bytes;
+        t.bytes += (size_t)kMaxBuildWaves * kNodeDxy;
+    }
+    return t;
 }
 
 // Levels worth building when no window is longer than max_window sites (0 = unknown: all).
-// Level k (k >= 3) has nodes of leaf*64^(k-1) sites; a window can only contain such a node if it
-// is at least that long.  Levels 1 and 2 always exist (the build kernels write them).
-inline int useful_levels_for(const TreeLayout &t, uint64_t leaf, uint64_t max_window) {
+// Level k (k >= 2) has nodes of leaf*64^(k-1) sites; a window can only contain such a node if it
+// is at least that long.  The levels the build kernel writes itself always exist: `built` = 2 for the f64
+// trees (levels 1 and 2 leave the streaming kernel together), 1 for the int8 tree, whose level 2 (65536 sites)
+// is a tree_up launch of its own — skipped for windows shorter than that (round 5: W = 50000).
+inline int useful_levels_for(const TreeLayout &t, uint64_t leaf, uint64_t max_window, int built = 2) {
     if (max_window == 0) return t.n_levels;
-    int k = 2;
-    uint64_t node = leaf * kRadix * kRadix;  // level-3 node
+    int k = built;
+    uint64_t node = leaf * kRadix;  // level-2 node
+    for (int j = 2; j <= built; ++j) node *= kRadix;  // the first level above the built ones
     while (k < t.n_levels && node <= max_window) {
         ++k;
         node *= kRadix;
@@ -77,7 +89,7 @@ inline int useful_levels_for(const TreeLayout &t, uint64_t leaf, uint64_t max_wi
     return k;
 }
 inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
-    return useful_levels_for(t, (uint64_t)leaf_sites(stat), max_window);
+    return useful_levels_for(t, (uint64_t)leaf_sites(stat), max_window, stat == PGT_STAT_HET ? 1 : 2);
 }
 
 // ---- allele-frequency front end (pgt_af_kernels.hip): nodes of V scalar sums, node-major ------

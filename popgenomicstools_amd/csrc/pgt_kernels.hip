@@ -79,6 +79,8 @@ struct TreeView {
     size_t pair_stride;    // bytes between the trees of consecutive pairs
     size_t off[kMaxLevels];
     int n_levels;
+    uint32_t n_partials;   // dxy: build waves that left a partial sum at `partials` (0: none, e.g. no sites)
+    size_t partials;       // dxy: byte offset of those sums (TreeLayout::partials)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -116,6 +118,7 @@ struct TreeView {
 // and lose at the next.  profiles/HISTORY.md A1-A2, profiles/r04/README.md.
 constexpr int kFstStage = 16;                         // tiles staged per wave: 16 KiB of LDS
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
+static_assert(kFstBuildBlocks * 4 == kMaxBuildWaves, "the dxy tree reserves one partial sum per build wave");
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
 constexpr uint64_t kFstSmallTiles = 40000;            // level-2 tiles (3.3e8 sites) up to which 16 loads per lane are kept in flight
 
@@ -134,6 +137,7 @@ struct NodeStage {
     Node *rows;  // LDS: [STAGE][64] of this wave
     Node *l1, *l2;
     uint64_t n_waves, first_t = 0;  // row k holds tile first_t + k * n_waves
+    Node sum = node_identity<Node>();  // of the level-2 nodes written so far, in tile order (wave-uniform; only the dxy builds read it)
     int lane, held = 0;
     __device__ __forceinline__ NodeStage(char *lds, int wib, int lane_, Node *l1_, Node *l2_, uint64_t n_waves_)
         : rows(reinterpret_cast<Node *>(lds) + (size_t)wib * STAGE * kWave), l1(l1_), l2(l2_), n_waves(n_waves_), lane(lane_) {}
@@ -145,6 +149,7 @@ struct NodeStage {
             else l1[t * kRadix + lane] = v;  // one 1-KiB coalesced wave store
             const Node top = node_wave_sum(v);
             if (lane == 0) l2[t] = top;
+            node_add(sum, top);
         }
         held = 0;
     }
@@ -301,14 +306,59 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
     else if (v == -9.0) acc.nskip += 1;
 }
 
+// THE COUNT COLUMNS BY 16-BYTE LOADS (round 5).  n1 / n2 are 4 B/site: with the f64 columns' layout (lane l owns sites 2l,
+// 2l+1 of a 128-site leaf tile) they were 8-byte loads (`global_load_dwordx2 nt`, a third of the kernel's bytes).  Now one
+// `global_load_dwordx4 nt` per lane covers 4 sites, a wave instruction 256 = the PAIR of leaf tiles j, j+1 (j even): lane L
+// holds sites 4L .. 4L+3 of the pair.  The only thing the counts decide is the predicate of dxyWindow.cpp:381 (`nind >=
+// minind` for both populations), so it is evaluated in THAT layout and transposed as four 64-bit ballots (wave-uniform,
+// scalar registers): bit L of mask c = site 4L + c of the pair.  The lane that owns sites 2l + q (q = 0, 1) of leaf tile h
+// (0, 1) of the pair — pair site 128h + 2l + q, i.e. count lane 32h + (l >> 1), component 2(l & 1) + q — picks its two bits
+// from the masks.  Integer-exact, the f64 arithmetic is untouched: rows bit for bit those of the 8-byte form.
+// MEASURED (interleaved A/B of the two builds in one process, profiles/r05/lib_ab_v1_*.md): a TIE — dxy 80.9 -> 79.8 and
+// 80.1 -> 79.9 % at 10^8 sites, 81.3 -> 82.6 and 80.9 -> 81.0 at 10^9; fused 80.3 -> 80.8 at 10^8.  The guide's 0.54-0.70x for
+// 8-byte nt accesses does not bind here: the kernel waits on HBM, not on the load unit.  Kept because every byte of every
+// build kernel is now read by a 16-byte load, the one width rocprofv3's FETCH_SIZE is calibrated for (profiles/r05).
+struct PairPred { unsigned long long m0, m1, m2, m3; };  // four scalars (an array of them lands in scratch)
+__device__ __forceinline__ PairPred count_pair_pred(const int4 &k1, const int4 &k2, int minind) {
+    return PairPred{__ballot(k1.x >= minind && k2.x >= minind), __ballot(k1.y >= minind && k2.y >= minind),
+                    __ballot(k1.z >= minind && k2.z >= minind), __ballot(k1.w >= minind && k2.w >= minind)};
+}
+template <int H, int Q>  // leaf tile H of the pair, site 2 * lane + Q of it
+__device__ __forceinline__ bool pair_pred_bit(const PairPred &p, int lane) {
+    // shift both candidate masks, then choose (choosing the 64-bit mask per lane first makes the compiler index a scratch copy)
+    const unsigned long long me = Q == 0 ? p.m0 : p.m1, mo = Q == 0 ? p.m2 : p.m3;  // even / odd lanes' mask
+    const uint32_t e = (H ? (uint32_t)(me >> 32) : (uint32_t)me) >> (lane >> 1);
+    const uint32_t o = (H ? (uint32_t)(mo >> 32) : (uint32_t)mo) >> (lane >> 1);
+    return (((lane & 1) ? o : e) & 1u) != 0;
+}
+__device__ __forceinline__ double dxy_site_pred(double p1, double p2, bool counted) {  // dxy_site with the predicate given
+    const double d = __dadd_rn(__dmul_rn(p1, __dsub_rn(1.0, p2)), __dmul_rn(p2, __dsub_rn(1.0, p1)));
+    return counted ? d : -9.0;
+}
+// leaf tile H of a pair: the two sites of this lane -> the leaf's node in every lane
+template <int H>
+__device__ __forceinline__ NodeDxy dxy_leaf_node(const double2 &x1, const double2 &x2, const PairPred &pp, int lane) {
+    NodeDxy acc{0.0, 0u, 0u};
+    dxy_acc(acc, dxy_site_pred(x1.x, x2.x, pair_pred_bit<H, 0>(pp, lane)));
+    dxy_acc(acc, dxy_site_pred(x1.y, x2.y, pair_pred_bit<H, 1>(pp, lane)));
+    return node_wave_sum(acc);
+}
+
 
 // ONE COLUMN AT A TIME here too (round 3, see fst_build_kernel): per batch of U = 4 leaf tiles the wave requests p1's
-// four kibibytes and waits, p2's and waits, then the two count columns together (eight 8-byte loads).  The per-site
+// four kibibytes and waits, p2's and waits, then the two count columns together (round 3: eight 8-byte loads; round 5: four
+// 16-byte loads, see count_pair_pred).  The per-site
 // value needs all four columns, so the bursts are separated by load fences instead of by consumption.  Interleaved
 // A/B, two boxes (profiles/r03/dxy_ab_*.txt; % of the HBM peak on 24 B/site, the round-2 form -> this one): 10^9 sites
 // 80.0 -> 81.4, 81.7 -> 83.7; 1.25e8 sites 74.5 -> 78.5, 77.1 -> 80.1; 10^8 sites 74.9 -> 79.4, 72.5 -> 75.6.  Waiting after
 // every column (n1 and n2 apart) loses 3-5 points, batches of 8 leaf tiles are no better, batches of 2 are latency-bound.
-template <int U = 4>  // leaf tiles per batch
+// Round 5, five more schedules of the same loads, all bit-identical, none ahead at both sizes (profiles/r05/README.md,
+// dxy_schedule_variants_rejected.patch): the count columns as 4-load bursts per 8 leaf tiles (ballots kept in scalar
+// registers; -0.9 / -2.8 points at 10^8 / 10^9 sites, with n1 awaited before n2 +1.8 / -2.4); the next batch's p1 burst requested
+// before this batch is computed (+0.5 / -1.6); super-batches of 8 or 16 leaf tiles in which EVERY stream is visited for two or
+// four consecutive 4-load bursts — counts, then p1 held in registers, then p2 consumed burst by burst as the fst build consumes
+// its column (-2.2 / -0.6 and -3.4 / +0.3).
+template <int U = 4>  // leaf tiles per batch (even: the count columns are read per PAIR of leaf tiles)
 __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, const double *__restrict__ p2,
                                                const int32_t *__restrict__ n1, const int32_t *__restrict__ n2,
                                                uint64_t n, int minind, uint64_t n_l2, const TreeView &tv, char *lds_stage) {
@@ -326,12 +376,12 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
         if (base + kTile2 <= n) {
             const double2 *__restrict__ q1 = reinterpret_cast<const double2 *>(p1 + base);
             const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(p2 + base);
-            const int2 *__restrict__ m1 = reinterpret_cast<const int2 *>(n1 + base);
-            const int2 *__restrict__ m2 = reinterpret_cast<const int2 *>(n2 + base);
+            const int4 *__restrict__ m1 = reinterpret_cast<const int4 *>(n1 + base);  // base is a multiple of 8192: 16-byte aligned
+            const int4 *__restrict__ m2 = reinterpret_cast<const int4 *>(n2 + base);
 #pragma unroll 1
             for (int j = 0; j < kRadix; j += U) {
                 double2 x1[U], x2[U];
-                int2 k1[U], k2[U];
+                int4 k1[U / 2], k2[U / 2];  // one 16-byte load per lane and PAIR of leaf tiles
 #pragma unroll
                 for (int u = 0; u < U; ++u) x1[u] = load16<true>(q1 + (j + u) * kWave + lane);
                 load_fence(x1[U - 1].y);
@@ -339,16 +389,16 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
                 for (int u = 0; u < U; ++u) x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
                 load_fence(x2[U - 1].y);
 #pragma unroll
-                for (int u = 0; u < U; ++u) k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+                for (int u = 0; u < U / 2; ++u) k1[u] = load16_nt(m1 + (j / 2 + u) * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < U; ++u) k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
+                for (int u = 0; u < U / 2; ++u) k2[u] = load16_nt(m2 + (j / 2 + u) * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    NodeDxy acc{0.0, 0u, 0u};
-                    dxy_acc(acc, dxy_site(x1[u].x, x2[u].x, k1[u].x, k2[u].x, minind));
-                    dxy_acc(acc, dxy_site(x1[u].y, x2[u].y, k1[u].y, k2[u].y, minind));
-                    acc = node_wave_sum(acc);
-                    if (lane == j + u) keep = acc;
+                for (int u = 0; u < U; u += 2) {
+                    const PairPred pp = count_pair_pred(k1[u / 2], k2[u / 2], minind);
+                    const NodeDxy a0 = dxy_leaf_node<0>(x1[u], x2[u], pp, lane);
+                    const NodeDxy a1 = dxy_leaf_node<1>(x1[u + 1], x2[u + 1], pp, lane);
+                    if (lane == j + u) keep = a0;
+                    if (lane == j + u + 1) keep = a1;
                 }
             }
         } else {
@@ -367,6 +417,12 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
         stage.put(t, keep);
     }
     stage.flush();
+    // THE GENOME-WIDE LINE WITHOUT UPPER LEVELS (round 5).  dxyWindow's last line (dxyWindow.cpp:382-385,429-433) is the sum over
+    // ALL sites; it used to be the query [0, n), for which every tree level above 2 had to be built: two or three
+    // tree_up launches of ~5 us each behind every dxy / fused build whose windows (W = 50000 sites) need none of them.
+    // Every wave now leaves the sum of the level-2 nodes it wrote (tile order), and the total is the sum of these <= 2048
+    // partials in wave order — fixed by the static grid, hence a function of the input alone.
+    if (lane == 0) reinterpret_cast<NodeDxy *>(tv.base + tv.partials)[wave0] = stage.sum;
 }
 
 __global__ __launch_bounds__(256) void dxy_build_kernel(const double *p1, const double *p2, const int32_t *n1,
@@ -419,7 +475,7 @@ __device__ __forceinline__ uint32_t het_count_packed(const uint4 &w) {  // nonmi
 
 template <int U = 4>  // dxy leaf tiles per batch
 __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
-    static_assert(kRadix % (2 * U) == 0, "a batch starts in the middle of the tile");
+    static_assert(kRadix % (2 * U) == 0 && U % 2 == 0, "a batch starts in the middle of the tile; counts are read per pair of leaf tiles");
     static_assert((uint64_t)kLeafF64 * kRadix == (uint64_t)kLeafI8 * kHetChunk, "a dxy level-2 tile is one het work item");
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
     const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -453,14 +509,14 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
         if (base + kTile2 <= n) {
             const double2 *__restrict__ q1 = reinterpret_cast<const double2 *>(f.p1 + base);
             const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(f.p2 + base);
-            const int2 *__restrict__ m1 = reinterpret_cast<const int2 *>(f.n1 + base);
-            const int2 *__restrict__ m2 = reinterpret_cast<const int2 *>(f.n2 + base);
+            const int4 *__restrict__ m1 = reinterpret_cast<const int4 *>(f.n1 + base);  // 16-byte loads: see count_pair_pred
+            const int4 *__restrict__ m2 = reinterpret_cast<const int4 *>(f.n2 + base);
             const uint4 *__restrict__ h0 = reinterpret_cast<const uint4 *>(f.g[0] + base);
             const uint4 *__restrict__ h1 = reinterpret_cast<const uint4 *>(f.g[1] + base);
 #pragma unroll 1
             for (int j = 0; j < kRadix; j += U) {
                 double2 x1[U], x2[U];
-                int2 k1[U], k2[U];
+                int4 k1[U / 2], k2[U / 2];
                 uint4 gb[kHetChunk];
                 const bool burst = j == 0 || j == kRadix / 2;  // wave-uniform: genotype column 0 / 1
                 if (burst) {  // the genotype column's 8 KiB: a burst of its own, awaited
@@ -476,16 +532,16 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
                 for (int u = 0; u < U; ++u) x2[u] = load16<true>(q2 + (j + u) * kWave + lane);
                 load_fence(x2[U - 1].y);
 #pragma unroll
-                for (int u = 0; u < U; ++u) k1[u] = load8_nt(m1 + (j + u) * kWave + lane);
+                for (int u = 0; u < U / 2; ++u) k1[u] = load16_nt(m1 + (j / 2 + u) * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < U; ++u) k2[u] = load8_nt(m2 + (j + u) * kWave + lane);
+                for (int u = 0; u < U / 2; ++u) k2[u] = load16_nt(m2 + (j / 2 + u) * kWave + lane);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    NodeDxy acc{0.0, 0u, 0u};
-                    dxy_acc(acc, dxy_site(x1[u].x, x2[u].x, k1[u].x, k2[u].x, f.minind));
-                    dxy_acc(acc, dxy_site(x1[u].y, x2[u].y, k1[u].y, k2[u].y, f.minind));
-                    acc = node_wave_sum(acc);
-                    if (lane == j + u) keep = acc;
+                for (int u = 0; u < U; u += 2) {
+                    const PairPred pp = count_pair_pred(k1[u / 2], k2[u / 2], f.minind);
+                    const NodeDxy a0 = dxy_leaf_node<0>(x1[u], x2[u], pp, lane);
+                    const NodeDxy a1 = dxy_leaf_node<1>(x1[u + 1], x2[u + 1], pp, lane);
+                    if (lane == j + u) keep = a0;
+                    if (lane == j + u + 1) keep = a1;
                 }
                 if (burst) {
 #pragma unroll
@@ -532,6 +588,7 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
     }
     stage.flush();
     hflush();
+    if (lane == 0) reinterpret_cast<NodeDxy *>(f.tv_dxy.base + f.tv_dxy.partials)[wave0] = stage.sum;  // see dxy_build_body
 }
 
 // ------------------------------------------------------------------------------------------
@@ -914,6 +971,30 @@ __device__ __forceinline__ typename Tr::Node range_partial(const typename Tr::Co
     return acc;
 }
 
+// The sum over ALL sites from the partial sums the build waves left (dxy: the genome-wide line); every lane returns a
+// partial, node_wave_sum of it is the total.  Fixed order: lane l adds partials l, l + 64, ... in turn.
+template <class Tr>
+__device__ __forceinline__ typename Tr::Node total_partial(const char *tree, const TreeView &tv, int lane) {
+    using Node = typename Tr::Node;
+    const Node *__restrict__ p = reinterpret_cast<const Node *>(tree + tv.partials);
+    Node acc = node_identity<Node>();
+    constexpr int kAhead = 8;  // loads in flight per lane: 2048 partials are 32 per lane
+    for (uint32_t i0 = 0; i0 < tv.n_partials; i0 += kAhead * kWave) {
+        Node v[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kWave + (uint32_t)lane;
+            v[u] = p[i < tv.n_partials ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kWave + (uint32_t)lane;
+            node_add(acc, i < tv.n_partials ? v[u] : node_identity<Node>());
+        }
+    }
+    return acc;
+}
+
 template <class Tr>
 __device__ __forceinline__ void query_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
                                            const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
@@ -934,22 +1015,23 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
         } else {
             wd = win[w];
         }
+        if (is_total) {  // wave-uniform
+            const typename Tr::Node acc = node_wave_sum(total_partial<Tr>(tree, tv, lane));
+            if (lane == 0) Tr::store_total(tot, acc);
+            continue;
+        }
         // clamp to the columns so that a corrupt table can never fault the GPU
         const uint64_t hi = wd.hi < n_sites ? wd.hi : n_sites;
         const uint64_t lo = wd.lo < hi ? wd.lo : hi;
-        const typename Tr::Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, lo, hi, lane, n_sites));
-        if (lane == 0) {
-            if (is_total) {
-                Tr::store_total(tot, acc);
-            } else {
-                uint32_t start = wd.start, end = wd.end;
-                if (!(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
-                    start = hi > lo ? pos[lo] : 0u;
-                    end = hi > lo ? pos[hi - 1] : 0u;
-                }
-                Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
-            }
+        // the window's coordinates are requested BEFORE the descent (they depend on the table row alone): their round trip
+        // overlaps the tree's instead of following it (round 5; the kernel is a chain of dependent round trips per window)
+        uint32_t start = wd.start, end = wd.end;
+        if (!(wd.flags & PGT_WIN_COORDS)) {  // fstWindow.cpp:71-72
+            start = hi > lo ? pos[lo] : 0u;
+            end = hi > lo ? pos[hi - 1] : 0u;
         }
+        const typename Tr::Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, lo, hi, lane, n_sites));
+        if (lane == 0) Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
     }
 }
 
@@ -1068,7 +1150,7 @@ __device__ __forceinline__ void query_slide_body(const typename Tr::Args &args, 
 
     for (uint64_t task = wave0; task < n_tasks; task += n_waves) {
         if (task == n_groups) {  // the genome-wide total (dxy)
-            const Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, 0, n_sites, lane, n_sites));
+            const Node acc = node_wave_sum(total_partial<Tr>(tree, tv, lane));
             if (lane == 0) Tr::store_total(tot, acc);
             continue;
         }
@@ -1214,7 +1296,7 @@ __device__ __forceinline__ void query_group_body(const typename Tr::Args &args, 
 
     for (uint64_t task = wave0; task < n_tasks; task += n_waves) {
         if (task == n_groups) {  // the genome-wide total (dxy)
-            const Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, 0, n_sites, lane, n_sites));
+            const Node acc = node_wave_sum(total_partial<Tr>(tree, tv, lane));
             if (lane == 0) Tr::store_total(tot, acc);
             continue;
         }
@@ -1484,6 +1566,8 @@ TreeView make_view(const TreeLayout &tl, void *tree, size_t pair_stride, int lev
     tv.base = static_cast<char *>(tree);
     tv.pair_stride = pair_stride;
     tv.n_levels = levels;
+    tv.n_partials = 0;
+    tv.partials = tl.partials;
     for (int k = 0; k < tl.n_levels; ++k) tv.off[k] = tl.offset[k];
     return tv;
 }
@@ -1691,11 +1775,12 @@ int launch_dxy(const uint32_t *pos, const double *p1, const double *p2, const in
                const Hints &hints) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TreeLayout tl = tree_layout(PGT_STAT_DXY, n);
-    // the genome-wide total is a query over [0,n): it wants every level
-    const TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, tot ? 0 : hints.max_window));
+    // the genome-wide total is the sum of the build waves' partial sums (dxy_build_body): it needs no level of its own
+    TreeView tv = make_view(tl, tree, tl.bytes, useful_levels(tl, PGT_STAT_DXY, hints.max_window));
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const dim3 grid(build_grid(tl.count[1], kFstBuildBlocks));
+        tv.n_partials = grid.x * 4;  // every wave of the grid writes one (waves without a tile: the identity)
         hipLaunchKernelGGL(dxy_build_kernel, grid, dim3(256), kFstStageBytes, s, p1, p2, n1, n2, n, minind, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "dxy_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(tl, tv, 1, s, err)) return rc;
@@ -1774,15 +1859,16 @@ int launch_dxy_het(const uint32_t *pos, const double *p1, const double *p2, cons
     const TreeLayout td = tree_layout(PGT_STAT_DXY, n), th = tree_layout(PGT_STAT_HET, n);
     char *base = static_cast<char *>(tree);
     const int lh = useful_levels(th, PGT_STAT_HET, hints.max_window);
-    const TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, tot ? 0 : hints.max_window));
+    TreeView tvd = make_view(td, base, td.bytes, useful_levels(td, PGT_STAT_DXY, hints.max_window));
     const TreeView tvh = make_view(th, base + td.bytes, th.bytes, lh);  // the two genotype trees, th.bytes apart
     TreeView tvh1 = tvh;
     tvh1.base += th.bytes;
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);  // == td.count[1]: a dxy level-2 tile is one het work item
-        DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], tvd, tvh};
         const dim3 grid(build_grid(td.count[1], kFstBuildBlocks));
+        tvd.n_partials = grid.x * 4;  // the genome-wide line: see launch_dxy
+        DxyHetBuildArgs f{p1, p2, n1, n2, {g1, g2}, n, minind, td.count[1], tvd, tvh};
         hipLaunchKernelGGL(dxy_het_build_kernel<>, grid, dim3(256), kDxyHetStageBytes, s, f);
         if (int rc = hip_fail(hipGetLastError(), "dxy_het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeDxy>(td, tvd, 1, s, err)) return rc;

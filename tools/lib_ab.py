@@ -64,7 +64,12 @@ def main():
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     BURST = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     dev = torch.device("cuda", 0)
-    ctx_b = pgt.Context(0)  # the tree's library
+    b_name = "the tree's libpgtwin.so"
+    if os.environ.get("AB_B_LIB"):  # B = another prebuilt library (a variant cross-compiled into tools/_ab/) instead of the tree's
+        _lib.load()  # the tree's own is built / checked once, then set aside
+        _lib._lib, _lib.LIB_PATH = None, os.path.abspath(os.environ["AB_B_LIB"])
+        b_name = os.path.relpath(_lib.LIB_PATH, ROOT)
+    ctx_b = pgt.Context(0)
     _lib._lib, _lib.LIB_PATH = None, old
     _lib.SYMBOLS = [x for x in _lib.SYMBOLS if x != "pgt_extreme_reduce_cols"]  # added in round 4: an older build lacks it, no config here calls it
     ctx_a = pgt.Context(0)
@@ -98,9 +103,9 @@ def main():
     if fr:
         configs.append(("AF front end, 8 populations", 64, lambda c: c.fst_af_reduce_dev(pos, fr, nsamp, win, out=af_out, tree=af_tree)))
         configs.append(("AF front end, 2 populations", 16, lambda c: c.fst_af_reduce_dev(pos, fr[:2], nsamp[:2], win, out=af_out, tree=af_tree)))
-    print(f"A = {os.path.relpath(old, ROOT)}, B = the tree's libpgtwin.so; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A, {BURST} call(s) per measurement\n")
-    print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms | step B - A paired |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print(f"A = {os.path.relpath(old, ROOT)}, B = {b_name}; {n:.0e} sites, W = {W}, S = {S}, {rounds} rounds of A B B A, {BURST} call(s) per measurement\n")
+    print("| config | A build ms | B build ms | B - A paired (median) | A % of 8 TB/s | B % | A step ms | B step ms | step B - A paired | rows A = B |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     if os.environ.get("AB_ONLY"):  # e.g. AB_ONLY=AF: only the configurations whose name contains the string
         configs = [c for c in configs if os.environ["AB_ONLY"] in c[0]]
     emax = int((ewin_h["hi"] - ewin_h["lo"]).max())
@@ -109,6 +114,12 @@ def main():
             c.set_max_window(emax if name.startswith("extreme") else 50_000)
         for c in (ctx_a, ctx_b, ctx_a, ctx_b):
             one(c, fn)
+        # rows of the two builds, bit for bit (every tensor a call returns except the tree workspace, which is its last)
+        def rows(c):
+            r = fn(c)
+            torch.cuda.synchronize()
+            return [t.clone() for t in r[:-1] if t is not None]
+        same = all(torch.equal(x, y) for x, y in zip(rows(ctx_a), rows(ctx_b)))
         ra, rb, diff, sdiff = [], [], [], []
         for _ in range(rounds):
             a1, b1, b2, a2 = burst(ctx_a, fn), burst(ctx_b, fn), burst(ctx_b, fn), burst(ctx_a, fn)
@@ -118,7 +129,7 @@ def main():
             sdiff += [b1[1] - a1[1], b2[1] - a2[1]]
         ma, mb = np.median([x[0] for x in ra]), np.median([x[0] for x in rb])
         print(f"| {name} | {ma:.4f} | {mb:.4f} | {np.median(diff) * 1e3:+.1f} us | {bps * n / ma / 8e7:.1f} | {bps * n / mb / 8e7:.1f} | "
-              f"{np.median([x[1] for x in ra]):.4f} | {np.median([x[1] for x in rb]):.4f} | {np.median(sdiff) * 1e3:+.1f} us |")
+              f"{np.median([x[1] for x in ra]):.4f} | {np.median([x[1] for x in rb]):.4f} | {np.median(sdiff) * 1e3:+.1f} us | {'yes' if same else 'NO'} |")
 
 
 if __name__ == "__main__":
