@@ -38,15 +38,19 @@ watchdog thread per rank).  A phase that overruns ends the rank with exit code 1
 wedged rank reads as "rank 3: phase 'gather timed' exceeded its deadline of 60 s", not as a driver timeout; only the
 peer-store transport (opt-in: --exchange both / peer) is DEGRADABLE: once the gather's line is secured, a peer phase
 that overruns makes rank 0 print that line with exchange_peer marked unavailable and every rank exit 0.  The collectives
-run on RCCL (backend nccl) after a probe all-reduce that is given 100 s on a helper thread; if RCCL cannot be brought up
+run on RCCL (backend nccl) after a probe all-reduce that is given 60 s on a helper thread; if RCCL cannot be brought up
 the ranks agree (over the gloo control group, which always exists) to stage the 4 MB of rows through the CPU instead and
-say so in config.collective_backend.  Budget of `--gpus 8` on the 10^9-site genome: < 180 s in all — imports ~20 s,
+say so at the top of the line ("degraded": true, "ok": false, the metric string names the fallback) and in
+config.collective_backend.  Budget of `--gpus 8` on the 10^9-site genome: < 180 s in all — imports ~20 s,
 init + probe ~15 s, columns ~5 s, gather timed ~1 s, rank 0's rebuild of the whole 20-GB genome + single-GPU scan ~15 s,
 roofline ~1 s; the deadlines (sum 480 s) stay inside the driver's 600 s.
 
 The default N=1 run also times BASELINE configs 2, 3 and 5 in their one-GPU form at 10^8 sites
 ("extra"; --headline-only skips them, e.g. under rocprofv3 --stats) and the reference CPU path on a
-bounded sample ("cpu_baseline").  Prints ONE JSON line on rank 0.
+bounded sample ("cpu_baseline").  That leg is also the run's LIVE PARITY CHECK: the TSV the reference prints for the
+sample (the first 5x10^7 sites = the first two chromosomes, ~5000 windows) is compared with the rows the timed GPU run
+produced for those windows — "rows_check": {"against": "reference fstWindow ...", "windows": k, "equal": true}; a mismatch
+gives "ok": false and exit code 3.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
@@ -235,11 +239,54 @@ BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
 SEED = 12345
 
 
-def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside=None):
+def fmt_g6(x):
+    """`%g` of C / the default ostream precision the reference prints with (fstWindow.cpp:88)."""
+    return "%g" % x
+
+
+def check_rows_against_tsv(tsv_path, table, win, run_len, n_sample, against):
+    """The LIVE parity check of the headline run (fstWindow.cpp:69-107,150-152): the reference's TSV for the first n_sample
+    sites against the rows the GPU produced for the whole genome in the timed run.  Comparable are the windows that end
+    inside the sample (the streaming machine emits them before it can know what follows); what the reference prints after
+    them belongs to the sample's truncated last chromosome.  Coordinates, midpoint, count and label exact; FST as printed
+    (`%g`), or — on a rounding boundary of the six printed digits — printed from a value within 1e-9 relative."""
+    rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)[:win.size]  # pair 0 = the first table
+    k = int(np.count_nonzero(win["hi"] <= n_sample))
+    assert np.all(win["hi"][:k] <= n_sample), "windows ending inside the sample are a prefix of the table"
+    with open(tsv_path) as fh:
+        ref_lines = fh.read().splitlines()
+    res = {"against": against, "windows": k, "reference_rows": len(ref_lines), "equal": False}
+    if len(ref_lines) < k:
+        res["mismatch"] = f"the reference printed {len(ref_lines)} rows, the GPU table has {k} windows ending inside the sample"
+        return res
+    rounding_boundary = 0
+    for i in range(k):
+        r = rows[i]
+        want = ["chr%d" % (int(win["label_run"][i]) + 1), str(int(r["start"])), str(int(r["end"])), str(int(r["mid"])), None, str(int(r["n"]))]
+        got = ref_lines[i].split("\t")
+        f = float(r["fst"])
+        ok = len(got) == 6 and all(w is None or w == g for w, g in zip(want, got))
+        if ok and got[4] != fmt_g6(f):
+            if got[4] in (fmt_g6(f * (1 + 1e-9)), fmt_g6(f * (1 - 1e-9))) or abs(float(got[4]) - f) <= 1e-9 * abs(f) + 1e-12:
+                rounding_boundary += 1
+            else:
+                ok = False
+        if not ok:
+            want[4] = fmt_g6(f)
+            res["mismatch"] = f"row {i}: reference {ref_lines[i]!r}, GPU {chr(9).join(want)!r}"
+            return res
+    res["equal"] = True
+    res["fst_on_a_rounding_boundary"] = rounding_boundary
+    res["tsv_sha256"] = hashlib.sha256("\n".join(ref_lines[:k]).encode()).hexdigest()
+    return res
+
+
+def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside=None, table=None, win=None):
     """The reference CPU path on this box's host cores, on a bounded sample of the same workload:
     the first n_sample sites written as the tool's text input, then the UNMODIFIED reference binary
     (oracle/_ref/fstWindow, kind "reference") — or, if that binary did not travel, our restatement
-    (oracle/liboracle.so, kind "port") — timed end to end, single-threaded like the reference.
+    (oracle/liboracle.so, kind "port") — timed end to end, single-threaded like the reference.  Its TSV goes to a file
+    (a few thousand rows) and is compared with the rows of the timed GPU run: -> (cpu_baseline, rows_check).
     beside: callable(done) run on the calling thread WHILE the CPU run goes on a worker thread (its clock is taken there):
     the sustained leg, which keeps the GPU busy for those ~12 s (one of this box's 256 cores launches kernels meanwhile)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -251,6 +298,7 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
     chr_ids = genome.chr_ids_np(0, n_sample)
     tmpdir = tempfile.mkdtemp(prefix="pgt_bench_")
     path = os.path.join(tmpdir, "sample.fst.txt")
+    tsv = os.path.join(tmpdir, "sample.windows.tsv")
     orc.write_fst_text(path, chr_ids, hp, ha, hb)
     ref = oracle_bind.ref_binary("fstWindow")
     kind = "reference" if ref else "port"
@@ -260,10 +308,10 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
         t0 = time.perf_counter()
         try:
             if ref:
-                with open(os.devnull, "w") as devnull:
-                    subprocess.run([ref, path, str(W), str(S)], stdout=devnull, check=True)
+                with open(tsv, "w") as out_fh:
+                    subprocess.run([ref, path, str(W), str(S)], stdout=out_fh, check=True)
             else:
-                assert orc.fst_text(path, W, S, os.devnull) == 0  # a ctypes call: the GIL is released while it runs
+                assert orc.fst_text(path, W, S, tsv) == 0  # a ctypes call: the GIL is released while it runs
             timing["dt"] = time.perf_counter() - t0
         except BaseException as e:  # noqa: BLE001 — reported on the calling thread
             timing["error"] = e
@@ -296,12 +344,20 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
                                 "columns_equal_resident": True}
         ing.free()
         del text
+    rows_check = None
+    if table is not None:
+        rows_check = check_rows_against_tsv(tsv, table, win, genome.run_len, n_sample,
+                                            "reference fstWindow (oracle/_ref/fstWindow, the unmodified reference source compiled)" if ref
+                                            else "oracle port (oracle/liboracle.so; the reference binary did not travel)")
     os.unlink(path)
+    os.unlink(tsv)
     os.rmdir(tmpdir)
     return {"value": n_sample / dt, "unit": "sites/s", "cores": 1, "kind": kind,
             "sample": f"first {n_sample} sites of the workload as text ({'oracle/_ref/fstWindow' if ref else 'oracle port'} "
-                      f"{W} {S}, parse included, stdout to /dev/null, {dt:.2f} s); host has {os.cpu_count()} logical cores, "
-                      f"the reference is single-threaded"}
+                      f"{W} {S}, parse included, stdout to a file, {dt:.2f} s); host has {os.cpu_count()} logical cores, "
+                      f"the reference is single-threaded",
+            "beside": ("the sustained GPU leg ran on another host thread meanwhile (one core launching kernels)" if beside is not None
+                       else "nothing")}, rows_check
 
 
 def timed_config(ctx, call, alg_bytes, reps=15):
@@ -490,8 +546,10 @@ def pmc_traffic(n, n_tables):
 def bring_up_collectives(world, rank, dev, ph):
     """-> (group for the data-path collectives, device their tensors live on, description).
     The default group is gloo over 127.0.0.1 (the control plane: agreement and verdict flags; it comes up wherever TCP does).
-    RCCL (backend nccl) is a second group, probed with one all-reduce on a helper thread that gets 100 s: if the probe
-    fails or does not return on ANY rank, all ranks agree over gloo to stage the rows through the CPU instead."""
+    RCCL (backend nccl) is a second group (created on the main thread, lazily), probed with one all-reduce on a helper thread
+    that gets 60 s (at most half of the init deadline): if the probe fails or does not return on ANY rank, all ranks agree over
+    gloo to stage the rows through the CPU instead — a DEGRADED run: "degraded": true at the top of the line, the metric
+    string says so, "ok" is false (the number is not the RCCL result the run was asked for); exit code 0 so that the line is kept."""
     import threading
     from datetime import timedelta
     dist.init_process_group("gloo", timeout=timedelta(seconds=max(30.0, ph.deadline_of("init"))))
@@ -500,25 +558,38 @@ def bring_up_collectives(world, rank, dev, ph):
         return None, torch.device("cpu"), f"{want} (REHEARSAL: PGT_BENCH_BACKEND)"
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")  # an abandoned probe must not abort the process later
     box = {}
+    # The GROUP is created here, on the main thread: new_group coordinates through the default (gloo) group and its store,
+    # and that group must never be used from two threads at once (the fallback agreement below uses it too).  Only the probe
+    # collective itself — the call that can hang when RCCL cannot reach a peer — runs on the helper thread.
+    try:
+        torch.cuda.set_device(dev)
+        # no device_id: the communicator is then created lazily by the first collective — on the helper thread, where a hang
+        # costs the probe its time share and nothing else (with device_id new_group itself would connect, here)
+        box["group"] = dist.new_group(backend="nccl", timeout=timedelta(minutes=30))  # nccl == RCCL on ROCm
+    except Exception as e:  # noqa: BLE001 — any failure means "no RCCL", the reason is reported
+        box["error"] = f"{type(e).__name__}: {e}"
 
     def probe():
         try:
+            fault_point(ph, "rccl probe")
             torch.cuda.set_device(dev)  # the current device is per thread
-            g = dist.new_group(backend="nccl", timeout=timedelta(minutes=30), device_id=dev)  # nccl == RCCL on ROCm
             t = torch.ones(1, dtype=torch.float32, device=dev)
-            dist.all_reduce(t, group=g)
+            dist.all_reduce(t, group=box["group"])
             box["sum"] = float(t.item())
-            box["group"] = g
-        except Exception as e:  # noqa: BLE001 — any failure means "no RCCL", the reason is reported
+        except Exception as e:  # noqa: BLE001
             box["error"] = f"{type(e).__name__}: {e}"
 
-    th = threading.Thread(target=probe, daemon=True)
-    th.start()
-    th.join(min(100.0, 0.85 * ph.deadline_of("init")))  # a first RCCL bring-up on an eight-GPU node can take tens of seconds
+    th = None
+    if "group" in box:
+        th = threading.Thread(target=probe, daemon=True)
+        th.start()
+        # half of the init deadline at most (the gloo bring-up above and the agreement below share it): a probe that never
+        # returns must leave the fallback room to happen before the watchdog's exit 124
+        th.join(min(60.0, 0.5 * ph.deadline_of("init")))  # a first RCCL bring-up on an eight-GPU node can take tens of seconds
     ok = 1 if (box.get("sum") == float(world)) else 0
-    why = box.get("error") or ("probe all-reduce did not return in time" if th.is_alive() else f"probe all-reduce gave {box.get('sum')}")
+    why = box.get("error") or ("probe all-reduce did not return in time" if th is not None and th.is_alive() else f"probe all-reduce gave {box.get('sum')}")
     flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo; the helper thread, if still alive, sits inside RCCL, not in this group
     if int(flag.item()) == 1:
         return box["group"], dev, "nccl (RCCL)"
     ph.say("RCCL unusable on some rank" + (f" (here: {why})" if not ok else "") + " — rows will be staged through the CPU over gloo")
@@ -670,20 +741,44 @@ def main():
         return res
 
     def roofline_events():
-        """HIP events on the launch stream, around the build pass only -> (avg build ms, avg query ms)"""
+        """The dominant kernel's average launch duration, by HIP events on the launch stream -> (build ms, query ms, detail).
+        K back-to-back launches of the BUILD ALONE (the same entry point with an empty window table: nothing but the build kernel
+        is launched) between two events, then K whole steps between two events: no event sits between two kernels, so the
+        figures are those of the timed region's own launches (an event record between kernels costs each of them ~1 %: with
+        the library's per-call profiling events build + query used to exceed the step they were part of).  query = step - build.
+        The per-call profiling events are still taken and reported in `detail` for comparison."""
         with ph("roofline"):
             scratch = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
+            no_win = win_d[:0]
+            K = max(5, min(args.steps, 20))
+
+            def avg_ms(fn):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(K):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / K
+
+            build_only = avg_ms(lambda: scan(mycols, no_win, scratch, tree))
+            whole_step = avg_ms(lambda: scan(mycols, win_d, scratch, tree))
             ctx.set_profiling(True)
             build_ms, query_ms = [], []
-            for _ in range(max(5, min(args.steps, 20))):
+            for _ in range(K):
                 scan(mycols, win_d, scratch, tree)
                 bm, qm = ctx.last_kernel_ms()
                 build_ms.append(bm)
                 query_ms.append(qm)
             ctx.set_profiling(False)
-        return float(np.mean(build_ms)), float(np.mean(query_ms))
+        detail = {"launches_per_figure": K, "build_only_ms": build_only, "whole_step_ms": whole_step,
+                  "per_call_profiling_events": {"build_ms": float(np.mean(build_ms)), "query_ms": float(np.mean(query_ms)),
+                                                "note": "an event between the build and the query launch of every call: inflates both"}}
+        return build_only, max(whole_step - build_only, 0.0), detail
 
-    def assemble(runs, build_avg, query_avg, extra, cpu, note=None):
+    def assemble(runs, build_avg, query_avg, extra, cpu, note=None, ref_check=None):
         """rank 0: the JSON line from the transports that have run so far."""
         usable = [r for r in runs if r["available"]]
         good = [r for r in usable if r["verified"] is not False]
@@ -694,7 +789,7 @@ def main():
             if r["mode"] == "peer" and r["verified"] and r["dt"] < head["dt"]:
                 head = r
         dt, table, head_mode = head["dt"], head["table"], head["mode"]
-        rows_check = None
+        rows_check = ref_check  # N = 1: the reference's own TSV for the CPU-baseline sample against this run's rows (or None: --no-cpu)
         if world > 1:
             rows_check = ("bitwise equal to the single-GPU scan of the whole genome" if can_verify else
                           ("skipped (--no-verify)" if args.no_verify else "skipped (weak-scaling genome too large to rebuild on one GPU)"))
@@ -717,9 +812,11 @@ def main():
         achieved = BYTES_PER_SITE * n_tables * n / (build_avg * 1e-3) / 1e9  # GB/s
         traffic, traffic_source = pmc_traffic(n, n_tables)
         per_gpu = [int(s_["site_hi"] - s_["site_lo"]) for s_ in shards]
+        degraded = world > 1 and "FALLBACK" in backend_desc  # RCCL could not be brought up: rows went through the CPU over gloo
         line = {
             "metric": ("genomic sites/sec for 2-pop FST window scan" if not pairs_mode else
-                       f"genomic sites/sec for the all-pairs FST window scan ({n_tables} population pairs per site)"),
+                       f"genomic sites/sec for the all-pairs FST window scan ({n_tables} population pairs per site)")
+                      + (" — DEGRADED: rows staged through the CPU over gloo, RCCL unavailable" if degraded else ""),
             "value": float(n_total) * args.steps / dt,
             "unit": "sites/s",
             "n_gpus": world,
@@ -732,7 +829,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             # every transport that ran delivered the single-GPU table (or was not verifiable by request)
-            "ok": all(r["verified"] is not False for r in usable),
+            "ok": all(r["verified"] is not False for r in usable) and (ref_check is None or bool(ref_check["equal"])) and not degraded,
+            "degraded": degraded,
             "config": {"workload": (f"fstWindow 2 pops x {n_total:.0e} sites total" if not pairs_mode else
                                     f"fstWindow all {n_tables} pairs of 8 populations x {n_total:.0e} sites total, one batched call per step,")
                                    + f" in {genome.run_len.size} chromosomes"
@@ -755,7 +853,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch of the build kernel (read + written)",
                          "traffic_source": traffic_source,
-                         "kernel_ms": build_avg, "query_kernel_ms": query_avg,
+                         "kernel_ms": build_avg, "query_kernel_ms": query_avg, "measured": roof_detail,
                          "algorithmic_bytes_per_launch": BYTES_PER_SITE * n_tables * n, "sites_per_launch": n},
             "cpu_baseline": cpu,
             "extra": extra,
@@ -786,7 +884,7 @@ def main():
         raise SystemExit(3)
     if rank == 0:
         sanity(runs[0]["table"])
-    build_avg, query_avg = roofline_events()
+    build_avg, query_avg, roof_detail = roofline_events()
     if len(modes) > 1:
         # the gather's line is secured: whatever the opt-in second transport does (a mapping that never returns, stores
         # that never land) can no longer cost the run its result
@@ -798,7 +896,7 @@ def main():
             print(f"bench.py: the table assembled by '{runs[1]['mode']}' DIFFERS from the single-GPU table of the same genome "
                   "(\"ok\": false in the line)", file=sys.stderr, flush=True)
 
-    extra, cpu = {}, None
+    extra, cpu, ref_check = {}, None, None
     if rank == 0 and world == 1 and not pairs_mode:
         if not args.headline_only:
             with ph("extra configs"):
@@ -815,15 +913,20 @@ def main():
                 sustained()
         if not args.no_cpu:
             with ph("cpu baseline"):  # with the sustained leg beside it (not in --headline-only runs: rocprofv3 traces every dispatch)
-                cpu = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra, beside=None if args.headline_only else sustained)
+                cpu, ref_check = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra, beside=None if args.headline_only else sustained,
+                                              table=runs[0]["table"], win=win)
         del sust_out
 
     if rank == 0:
-        print(assemble(runs, build_avg, query_avg, extra, cpu), flush=True)
+        print(assemble(runs, build_avg, query_avg, extra, cpu, ref_check=ref_check), flush=True)
     ph.say("line printed" if rank == 0 else "done")
     all_ok = all(r["verified"] is not False for r in runs if r["available"])
     ctx.close()
     ph.close()
+    if ref_check is not None and not ref_check["equal"]:  # N = 1: the timed run's rows differ from the reference's TSV
+        print("bench.py: rows of the timed run DIFFER from the reference's TSV on the CPU-baseline sample: " + ref_check.get("mismatch", "?"),
+              file=sys.stderr, flush=True)
+        sys.exit(3)
     if world > 1:
         dist.barrier()
         sys.stdout.flush()

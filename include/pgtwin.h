@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define PGT_ABI_VERSION 4
+/* 5 (round 5): the i32 count columns of the dxy entry points must be 16-byte aligned (8 sufficed); pgt_tree_bytes(PGT_STAT_DXY)
+ * includes the build waves' partial sums; pgt_extreme_reduce_cols, PGT_TOK_CHR_PREFIX and 12 tokens per line (added under
+ * version 4 in round 4) are part of it.  A binding written for one version never calls a library of another. */
+#define PGT_ABI_VERSION 5
 
 enum {
     PGT_OK = 0,
@@ -328,7 +331,7 @@ enum {
     PGT_TOK_FREQ = 6, /* double that must lie in [0,1] (MAF allele frequency), else the line is an error */
     PGT_TOK_CHR_PREFIX = 7 /* as PGT_TOK_CHR (allowed as tokens[0] only), the chromosome being the token UP TO ITS FIRST '_':
                             * selscan locus ids `chr_position` (extractChr, ihsWindow.cpp:80-92; xpehhWindow.cpp:82-94); a token
-                            * without '_' is the name as a whole.  Added in round 4 (additive: ABI version unchanged) */
+                            * without '_' is the name as a whole (ABI 5) */
 };
 typedef struct pgt_ingest pgt_ingest;
 /* reductions over DEVICE columns (pgt_ingest_column) with the window table and the rows in HOST memory:

@@ -13,7 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpgtwin.so")
 
-PGT_ABI_VERSION = 4
+PGT_ABI_VERSION = 5
 PGT_OK, PGT_EARG, PGT_ECAP, PGT_EDEVICE, PGT_EDOMAIN, PGT_ENOMEM = range(6)
 PGT_WIN_COORDS = 1
 PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY, PGT_STAT_EXT = 0, 1, 2, 3
@@ -157,10 +157,14 @@ def load() -> C.CDLL:
     lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, vp]
-    for name in SYMBOLS:  # fail at load time, not at first use, if the library is older than the binding
-        getattr(lib, name)
-    if lib.pgt_abi_version() != PGT_ABI_VERSION:  # argument lists changed between ABI versions: never call across them
-        raise RuntimeError(f"libpgtwin.so has ABI version {lib.pgt_abi_version()}, this binding is written for {PGT_ABI_VERSION}")
+    # fail at load time, not at first use, and say what is wrong: the version first (argument lists changed between ABI
+    # versions: never call across them), then any symbol the binding declares and the library lacks
+    if lib.pgt_abi_version() != PGT_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.pgt_abi_version()}, this binding is written for {PGT_ABI_VERSION}")
+    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} is older than this binding although it reports ABI version {PGT_ABI_VERSION}: it lacks "
+                           + ", ".join(missing) + " (rebuild: python -m popgenomicstools_amd.build --force)")
     _lib = lib
     return lib
 

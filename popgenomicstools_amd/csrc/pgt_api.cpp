@@ -523,7 +523,7 @@ int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src,
 int pgt_extreme_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_score, uint64_t n, int mode, double cutoff,
                             const pgt_win *win, uint64_t n_win, pgt_ext_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
-    if ((n && (!d_pos || !d_score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    if ((n && (!d_pos || !d_score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce_cols: NULL argument");
     if (int rc = room_check(ctx, "pgt_extreme_reduce_cols", n_win, sizeof(pgt_ext_row), out_bytes)) return rc;
     if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
     const HintScope hint(ctx, win, n_win);

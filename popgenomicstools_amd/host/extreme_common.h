@@ -80,9 +80,21 @@ inline int run_extreme(const char *path, bool skip_header, int score_field, uint
     for (int k = 2; k < score_tok; ++k) spec[k] = PGT_TOK_SKIP;
     spec[score_tok] = PGT_TOK_F64;
     // (several GPUs: each holds its piece of the text and its slice of the columns)
-    if (resident_limit(b, b + (size_t)(text.end() - b) / device.count(), 4 + 8, [&] { return device.get(); }) != 0)
-        die("libpgtwin: the table does not fit the GPU's memory in one piece and the extreme-score tools have no passes mode "
-            "(give more GPUs with PGT_DEVICES=0,1,..)");
+    // The limit is PER GPU (PGT_MAX_RESIDENT_SITES, or what the free memory holds of a per-GPU share of this text) and is
+    // compared with the table's REAL line count: a limit the table stays under refuses nothing (round 5: any positive
+    // PGT_MAX_RESIDENT_SITES used to refuse every table).
+    if (const uint64_t per_gpu = resident_limit(b, b + (size_t)(text.end() - b) / device.count(), 4 + 8, [&] { return device.get(); })) {
+        uint64_t lines = (uint64_t)std::count(b, text.end(), '\n');
+        if (text.end() > b && text.end()[-1] != '\n') ++lines;
+        const uint64_t gpus = device.count();
+        const uint64_t fits = per_gpu > UINT64_MAX / gpus ? UINT64_MAX : per_gpu * gpus;
+        if (lines > fits) {
+            const char *env = std::getenv("PGT_MAX_RESIDENT_SITES");
+            die("libpgtwin: the table has " + std::to_string(lines) + " lines, more than the " + std::to_string(fits) + " SNPs that fit (" +
+                (env ? "PGT_MAX_RESIDENT_SITES=" + std::string(env) : std::string("the free memory")) + " x " + std::to_string(gpus) +
+                " GPU" + (gpus > 1 ? "s" : "") + "), and the extreme-score tools have no passes mode (give more GPUs with PGT_DEVICES=0,1,..)");
+        }
+    }
 
     ScoreTable tab;
     tab.score_field = score_field;

@@ -1,6 +1,8 @@
 """Multi-rank worker with the REAL HIP kernels, for the one-GPU box: started by tests/test_gpu_parity.py as
     python -m torch.distributed.run --nproc-per-node R tests/hip_rank_worker.py
 (gloo for the collectives, every rank on GPU 0 — the launcher runs before anything touches the GPU).
+On a box with several GPUs tests/test_multi_gpu.py starts the same worker with PGT_TEST_DEVICE_PER_RANK=1 (rank r on GPU r)
+and PGT_TEST_BACKEND=nccl (the row collectives on an RCCL group, device tensors): the real transport, over xGMI.
 Each rank materialises only its own site range of one counter-based synthetic genome, reduces its
 block of the window table through the C-ABI device entry points, and the rows travel to rank 0 through
 popgenomicstools_amd.distributed (both transports: the gather, and peer stores into rank 0's row
@@ -27,9 +29,14 @@ from synth_genome import SynthGenome  # noqa: E402
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    dev, cpu = torch.device("cuda", 0), torch.device("cpu")
-    ctx = pgt.Context(0)
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("PGT_TEST_DEVICE_PER_RANK") == "1" else 0
+    torch.cuda.set_device(dev_index)
+    dev, cpu = torch.device("cuda", dev_index), torch.device("cpu")
+    group = None
+    if os.environ.get("PGT_TEST_BACKEND") == "nccl":  # RCCL for the rows (device tensors); gloo stays the control plane
+        group = dist.new_group(backend="nccl")
+        cpu = dev  # `cpu` names the device the collectives' tensors live on, below
+    ctx = pgt.Context(dev_index)
     n, W, S = 3_000_000, 50_000, 10_000
     g = SynthGenome(4242, n, 5)
     win = pgt.build_windows_sites(g.run_len, W, S)
@@ -47,7 +54,7 @@ def main():
                                          FST_ROW_DTYPE).tobytes())
     for mode in ("gather", "peer", "peer_or_gather", "auto"):
         got = sharded_scan(win, FST_ROW_DTYPE, lambda lo, hi: g.fst_columns_t(lo, hi, dev), fst_reduce, dev,
-                           ctx=ctx, mode=mode, coll_device=cpu)
+                           ctx=ctx, mode=mode, coll_device=cpu, group=group)
         if rank == 0:
             assert got.size == win.size and got.tobytes() == ref, f"fst {mode}"
             print(f"HIP_RANKS_OK fst {mode}", flush=True)
@@ -64,7 +71,7 @@ def main():
     ref = whole(lambda: rows_from_device(ctx.fst_reduce_pairs_dev(*pair_cols(0, n), windows_to_device(win, dev))[0],
                                          FST_ROW_DTYPE).tobytes())
     for mode in ("gather", "peer"):
-        got = sharded_scan(win, FST_ROW_DTYPE, pair_cols, pairs_reduce, dev, tables=n_pairs, ctx=ctx, mode=mode, coll_device=cpu)
+        got = sharded_scan(win, FST_ROW_DTYPE, pair_cols, pairs_reduce, dev, tables=n_pairs, ctx=ctx, mode=mode, coll_device=cpu, group=group)
         if rank == 0:
             assert got.size == n_pairs * win.size and got.tobytes() == ref, f"pairs {mode}"
             print(f"HIP_RANKS_OK pairs {mode}", flush=True)
@@ -80,7 +87,7 @@ def main():
     ref = whole(lambda: rows_from_device(ctx.fst_af_reduce_dev(*af_cols(0, n), nsamp, windows_to_device(win, dev))[0],
                                          FST_ROW_DTYPE).tobytes())
     got = sharded_scan(win, FST_ROW_DTYPE, af_cols, af_reduce, dev, tables=n_pops * (n_pops - 1) // 2, ctx=ctx,
-                       mode="peer", coll_device=cpu)
+                       mode="peer", coll_device=cpu, group=group)
     if rank == 0:
         assert got.tobytes() == ref, "af"
         print("HIP_RANKS_OK af peer", flush=True)
@@ -100,7 +107,7 @@ def main():
         ctx.extreme_reduce_dev(c[0], c[1], PGT_EXT_IHS, 2.0, windows_to_device(w, dev), out=out)
     ref = whole(lambda: rows_from_device(ctx.extreme_reduce_dev(*ext_cols(0, n), PGT_EXT_IHS, 2.0, windows_to_device(ewin, dev))[0],
                                          EXT_ROW_DTYPE).tobytes())
-    got = sharded_scan(ewin, EXT_ROW_DTYPE, ext_cols, ext_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu)
+    got = sharded_scan(ewin, EXT_ROW_DTYPE, ext_cols, ext_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu, group=group)
     if rank == 0:
         assert int((ewin["hi"] - ewin["lo"]).max()) >= 1 << 20
         assert got.tobytes() == ref, "extreme"
@@ -115,7 +122,7 @@ def main():
     def het_reduce(c, w, out):
         ctx.het_reduce_dev(c[0], c[1], windows_to_device(w, dev), out=out)
     ref = whole(lambda: rows_from_device(ctx.het_reduce_dev(*het_cols(0, n), windows_to_device(win, dev))[0], HET_ROW_DTYPE).tobytes())
-    got = sharded_scan(win, HET_ROW_DTYPE, het_cols, het_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu)
+    got = sharded_scan(win, HET_ROW_DTYPE, het_cols, het_reduce, dev, ctx=ctx, mode="peer", coll_device=cpu, group=group)
     if rank == 0:
         assert got.tobytes() == ref, "het"
         print("HIP_RANKS_OK het peer", flush=True)
@@ -139,7 +146,7 @@ def main():
         for v in brow["sum"].tolist():
             acc += v
     for mode in ("gather", "peer"):
-        rows, total = sharded_dxy_scan(win, n, dxy_cols, ctx, minind, dev, mode=mode, coll_device=cpu)
+        rows, total = sharded_dxy_scan(win, n, dxy_cols, ctx, minind, dev, mode=mode, coll_device=cpu, group=group)
         if rank == 0:
             assert rows.tobytes() == ref_rows, f"dxy rows {mode}"
             assert int(total["neff"]) == int(ref_tot["neff"]) and int(total["nskip"]) == int(ref_tot["nskip"])

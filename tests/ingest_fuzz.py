@@ -175,11 +175,22 @@ def main():
                 keep_failure(d, cmd, {"single": a, "hybrid": c})
                 sys.exit(1)
             counts["hybrid"] = counts.get("hybrid", 0) + 1
-        if kind in ("ihs", "xpehh"):  # no passes mode: an input beyond the limit is refused, nothing printed
-            c = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PGT_MAX_RESIDENT_SITES="70000"), timeout=120)
-            if not (c.returncode == 255 and c.stdout == b"" and b"no passes mode" in c.stderr):
-                print("MISMATCH (refusal beyond the resident limit)", cmd, c.returncode, c.stderr[-200:], "files kept in", d)
-                sys.exit(1)
+        if kind in ("ihs", "xpehh"):  # no passes mode: an input REALLY beyond the per-GPU limit is refused, nothing printed; one under it runs as ever
+            with open(f, "rb") as fh:
+                data = fh.read()
+            n_lines = data.count(b"\n") + (1 if data and not data.endswith(b"\n") else 0)
+            for limit, gpus in ((max(n_lines - 1, 1), 1), (n_lines, 1), (n_lines + 5, 1), ((n_lines + 1) // 2, 2), (max((n_lines - 1) // 2, 1), 2)):
+                env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))
+                if gpus == 2:
+                    env["PGT_DEVICES"] = "0,0"
+                c = subprocess.run(cmd, capture_output=True, env=env, timeout=120)
+                if n_lines > limit * gpus:
+                    ok = c.returncode == 255 and c.stdout == b"" and b"no passes mode" in c.stderr and b"PGT_MAX_RESIDENT_SITES=" in c.stderr
+                else:
+                    ok = (c.returncode, c.stdout, c.stderr) == (a.returncode, a.stdout, a.stderr)
+                if not ok:
+                    print("MISMATCH (resident limit %d x %d GPUs, %d lines)" % (limit, gpus, n_lines), cmd, c.returncode, c.stderr[-200:], "files kept in", d)
+                    sys.exit(1)
         elif True:  # in passes (as for a table larger than the GPU): same rows; a bad line ends the run after the earlier blocks' rows
             limit = int(rng.choice([1, 70000, 150000]))
             env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))

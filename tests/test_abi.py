@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
-    assert lib.pgt_abi_version() == 4 == _lib.PGT_ABI_VERSION
+    assert lib.pgt_abi_version() == 5 == _lib.PGT_ABI_VERSION
     # struct sizes as the header lays them out
     assert _lib.WIN_DTYPE.itemsize == 32 and _lib.FST_ROW_DTYPE.itemsize == 40
     assert _lib.HET_ROW_DTYPE.itemsize == 32 and _lib.DXY_ROW_DTYPE.itemsize == 24

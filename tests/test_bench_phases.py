@@ -92,3 +92,49 @@ def test_pmc_traffic_follows_the_kernel_source_hash(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     t, why = bench.pmc_traffic(10**9, 1)
     assert t is None and "other kernel sources" in why
+
+
+def test_rows_check_against_the_reference_tsv(tmp_path):
+    """bench.py's live parity check (N = 1): rows of the WHOLE genome against the TSV the reference tool prints for a SAMPLE
+    of it — also when the sample cuts a chromosome (the rows the reference prints after the last comparable window belong
+    to its truncated tail and are ignored) — and a single differing count, coordinate or sixth digit is reported."""
+    import numpy as np
+    import oracle_bind
+    import synth
+    import popgenomicstools_amd as pgt
+    from popgenomicstools_amd._lib import FST_ROW_DTYPE
+
+    orc = oracle_bind.load()
+    rng = np.random.default_rng(5)
+    n, W, S = 60_000, 5_000, 1_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    run_len = np.bincount(chr_ids).astype(np.uint64)
+    win = pgt.build_windows_sites(run_len, W, S)
+    ref = orc.fst_scan(chr_ids, pos, a, b, W, S)
+    assert ref.size == win.size
+    table = np.zeros(win.size, dtype=FST_ROW_DTYPE)
+    for f in ("start", "end", "mid", "n"):
+        table[f] = ref[f]
+    table["fst"] = ref["value"]
+    binary = oracle_bind.ref_binary("fstWindow")
+    for n_sample in (n, int(run_len[0] + run_len[1]), int(run_len[0] + run_len[1] // 2)):  # whole, two chromosomes, a cut one
+        text, tsv = str(tmp_path / "in.txt"), str(tmp_path / "out.tsv")
+        orc.write_fst_text(text, chr_ids[:n_sample], pos[:n_sample], a[:n_sample], b[:n_sample])
+        if binary:
+            with open(tsv, "w") as fh:
+                subprocess.run([binary, text, str(W), str(S)], stdout=fh, check=True)
+        else:
+            assert orc.fst_text(text, W, S, tsv) == 0
+        res = bench.check_rows_against_tsv(tsv, table, win, run_len, n_sample, "test")
+        k = int(np.count_nonzero(win["hi"] <= n_sample))
+        assert res["equal"] is True and res["windows"] == k and k > 10 and res["reference_rows"] >= k, res
+        for field, delta in (("n", 1), ("end", 1), ("fst", 1e-5)):
+            bad = table.copy()
+            bad[field][k // 2] += type(bad[field][0])(delta) if field != "fst" else abs(bad["fst"][k // 2]) * delta + 1e-7
+            res = bench.check_rows_against_tsv(tsv, bad, win, run_len, n_sample, "test")
+            assert res["equal"] is False and f"row {k // 2}:" in res["mismatch"], (field, res)
+        # within 1e-9 relative: still the same printed digits (or a rounding boundary, which is accepted)
+        near = table.copy()
+        near["fst"] *= 1 + 5e-10
+        assert bench.check_rows_against_tsv(tsv, near, win, run_len, n_sample, "test")["equal"] is True

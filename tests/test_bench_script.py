@@ -131,7 +131,7 @@ def test_bench_second_transport_that_never_returns_degrades_to_the_gather_line()
 def test_bench_falls_back_to_cpu_staged_rows_when_rccl_cannot_be_brought_up():
     """Two ranks on ONE GPU without the rehearsal backend knob: RCCL refuses (or never finishes) a communicator with two
     ranks on the same device, so this is the real thing the fallback exists for — the probe all-reduce fails or overruns its
-    100 s on the helper thread, the ranks agree over the gloo control group, the rows are staged through the CPU, the line
+    60 s on the helper thread, the ranks agree over the gloo control group, the rows are staged through the CPU, the line
     says so, the table is still the single-GPU table bit for bit."""
     env = _rehearsal_env()
     env.pop("PGT_BENCH_BACKEND")
@@ -140,16 +140,33 @@ def test_bench_falls_back_to_cpu_staged_rows_when_rccl_cannot_be_brought_up():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env,
                        timeout=600)
     two = _line(r)
-    assert two["ok"] is True and two["rows_sha256"] == one["rows_sha256"] and two["rows_check"].startswith("bitwise equal")
+    assert two["rows_sha256"] == one["rows_sha256"] and two["rows_check"].startswith("bitwise equal")
     assert "FALLBACK" in two["config"]["collective_backend"], two["config"]["collective_backend"]
     assert "RCCL unusable" in r.stderr
+    # a CPU-staged number is not the RCCL result the run was asked for: said at the top of the line, not only in config
+    assert two["degraded"] is True and two["ok"] is False and "DEGRADED" in two["metric"] and one["degraded"] is False
+
+
+@pytest.mark.timeout(600)
+def test_bench_rccl_probe_that_never_returns_still_falls_back():
+    """The probe all-reduce HANGS on rank 1 (fault injected on the helper thread, as an RCCL bootstrap that never completes
+    would): the main threads give it its share of the init deadline, agree over gloo, stage the rows through the CPU — the
+    advertised fallback, not the watchdog's exit 124 — and the line says degraded."""
+    env = _rehearsal_env()
+    env.pop("PGT_BENCH_BACKEND")
+    env.update(PGT_BENCH_FAULT="1:rccl probe:hang", PGT_BENCH_DEADLINE_SCALE="0.25")  # init: 30 s, the probe gets 15 s of it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env,
+                       timeout=500)
+    two = _line(r)
+    assert two["degraded"] is True and two["ok"] is False and two["rows_check"].startswith("bitwise equal")
+    assert "fault injected: hang in phase 'rccl probe'" in r.stderr and "did not return in time" in r.stderr
 
 
 @pytest.mark.timeout(600)
 def test_rccl_probe_brings_up_a_communicator_beside_the_gloo_control_group():
     """bench.bring_up_collectives as the ranks of an N > 1 run call it — gloo default group, RCCL as a second group created
-    and probed on a helper thread — with the one rank a 1-GPU box allows: the API sequence (new_group(backend="nccl",
-    device_id=...) on top of a gloo default group, all-reduce, agreement over gloo) is what the 8-GPU run executes."""
+    on the main thread, probed on a helper thread — with the one rank a 1-GPU box allows: the API sequence (new_group(backend="nccl")
+    on top of a gloo default group, all-reduce, agreement over gloo) is what the 8-GPU run executes."""
     code = """
 import os, sys, json
 sys.argv = ['bench.py']

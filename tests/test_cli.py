@@ -419,8 +419,18 @@ def test_extreme_cli_large_table_all_paths_agree_and_errors_keep_their_line_numb
         r = run([hosts_ext["ihsWindow"], str(ihs), "-winsize", "50000"], env=dict(os.environ, **e))
         assert r.returncode == 255 and r.stdout == "" and f"line {bad_at + 1} of" in r.stderr, (e, r.stderr[-300:])
     ihs.write_text("".join(lines))
+    # PGT_MAX_RESIDENT_SITES is a limit PER GPU compared with the table's real line count: beyond it the tools refuse (they
+    # have no passes mode) and say which limit it was; a limit the table stays under changes nothing
     r = run([hosts_ext["ihsWindow"], str(ihs)], env=dict(os.environ, PGT_MAX_RESIDENT_SITES="100000"))
     assert r.returncode == 255 and r.stdout == "" and "no passes mode" in r.stderr
+    assert f"{len(lines)} lines" in r.stderr and "PGT_MAX_RESIDENT_SITES=100000 x 1 GPU" in r.stderr
+    r = run([hosts_ext["ihsWindow"], str(ihs)], env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(len(lines) // 2 - 1), PGT_DEVICES="0,0"))
+    assert r.returncode == 255 and r.stdout == "" and "x 2 GPUs" in r.stderr
+    plain = run([hosts_ext["ihsWindow"], str(ihs)])
+    for env in ({"PGT_MAX_RESIDENT_SITES": str(len(lines))}, {"PGT_MAX_RESIDENT_SITES": str(len(lines) // 2), "PGT_DEVICES": "0,0"},
+                {"PGT_MAX_RESIDENT_SITES": "10000000"}):
+        r = run([hosts_ext["ihsWindow"], str(ihs)], env=dict(os.environ, **env))
+        assert (r.returncode, r.stdout) == (0, plain.stdout) and plain.returncode == 0, (env, r.stderr[-300:])
 
 
 @pytest.mark.gpu

@@ -72,6 +72,10 @@ def main():
     ctx_b = pgt.Context(0)
     _lib._lib, _lib.LIB_PATH = None, old
     _lib.SYMBOLS = [x for x in _lib.SYMBOLS if x != "pgt_extreme_reduce_cols"]  # added in round 4: an older build lacks it, no config here calls it
+    import ctypes
+    a_abi = ctypes.CDLL(old).pgt_abi_version()
+    assert a_abi in (4, 5), a_abi  # 4 -> 5 changed no argument list (alignment of the i32 columns, the dxy workspace size): safe to call for this tool
+    _lib.PGT_ABI_VERSION = a_abi
     ctx_a = pgt.Context(0)
     assert ctx_a._lib is not ctx_b._lib
     for c in (ctx_a, ctx_b):
