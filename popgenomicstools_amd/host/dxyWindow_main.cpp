@@ -9,6 +9,10 @@
 // defined when both files list identical or nested site sets.  This host
 // computes the intersection of the two files by (chromosome run, position), which is what the
 // reference produces on that domain, and is defined outside it as well.
+// PGT_DXY_SYNC=reference (an environment switch, the CLI surface is unchanged) replays those loops
+// instead — pair_as_the_reference() below — so that inputs on which the reference terminates
+// normally but oddly (a position coincidence across chromosomes, an extra Pop2 site at a
+// chromosome end, no shared site) print the reference's bytes: INTEGRATION.md §3a.
 #include <map>
 
 #include "host_common.h"
@@ -125,6 +129,69 @@ static void read_maf(const char *path, const char *which, Maf &m, ColumnCache &c
         cols[0].data = m.pos.data(); cols[1].data = m.freq.data(); cols[2].data = m.nind.data();
         cache.store(m.n, m.runs, cols);
     }
+}
+
+// ---- PGT_DXY_SYNC=reference: dxyWindow.cpp:315-331 replayed over the two parsed site lists ----------------------------
+// The reference keeps one current line per file and, when chromosome or position differ, advances ONE of them:
+//   Pop1 (`:317-323`) when the names agree and Pop1's position is smaller, or the names differ and Pop2's name is not the
+//        chromosome of the last processed site — until the POSITIONS are equal (names are not looked at), or Pop1 ends;
+//   Pop2 (`:324-330`) otherwise — while its position is SMALLER — and gives the whole run up unless the positions then agree.
+// What it then processes is Pop1's line with Pop2's frequency and count beside it, under Pop1's chromosome name (`:332`).  A
+// give-up ends the main loop exactly as the end of a file does (`:323,329` break to `:406`), so the reference's output is that
+// of its window machine on the pairs processed so far: the list this function returns.  "getline fails" is "no further
+// parsed line" here (both parsers stop at the first empty line as `while (!maf1line.empty())` does, `:313`).
+// -> the pairs (index in file 1, index in file 2); `last_chr`: the chromosome the closing code (`:407-426`) works on —
+// the last pair's, or the first line's when nothing was paired.
+static std::vector<std::pair<size_t, size_t>> pair_as_the_reference(const Maf &m1, const Maf &m2, std::string &last_chr) {
+    auto run_of = [](const Runs &r) {  // site index -> run index, by a cursor that only moves forward
+        return [&r, run = (size_t)0, end = (size_t)(r.len.empty() ? 0 : r.len[0])](size_t i) mutable {
+            while (i >= end && run + 1 < r.len.size()) end += r.len[++run];
+            return run;
+        };
+    };
+    auto r1 = run_of(m1.runs), r2 = run_of(m2.runs);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    size_t i = 0, j = 0;
+    std::string chr = m1.runs.name[0];
+    for (;;) {
+        const std::string &c1 = m1.runs.name[r1(i)], &c2 = m2.runs.name[r2(j)];
+        if (m1.pos[i] != m2.pos[j] || c1 != c2) {  // :316
+            if ((c1 == c2 && m1.pos[i] < m2.pos[j]) || (c1 != c2 && c2 != chr)) {  // :317
+                while (m1.pos[i] != m2.pos[j] && i + 1 < m1.n) ++i;  // :319-322
+                if (m1.pos[i] != m2.pos[j]) break;                     // :323
+            } else {
+                while (m2.pos[j] < m1.pos[i] && j + 1 < m2.n) ++j;    // :326-329
+                if (m1.pos[i] != m2.pos[j]) break;                     // :330
+            }
+        }
+        chr = m1.runs.name[r1(i)];  // :332
+        pairs.emplace_back(i, j);
+        if (i + 1 >= m1.n) break;   // :399
+        ++i;
+        if (j + 1 >= m2.n) break;   // :402
+        ++j;
+    }
+    last_chr = chr;
+    return pairs;
+}
+
+// The reference's closing code on a chromosome of `len` base pairs of which NO site was processed (`:407-426` with nsites = 0,
+// positer = 1): every slot is a placeholder, every window `chr start end 0 0 0` (case H10 of tests/golden/dxy_hand_walked.json).
+static void print_placeholder_chromosome(const std::string &chr, uint64_t len, uint64_t W, uint64_t S, int skip_missing) {
+    if (skip_missing) return;  // neffective == 0: the row is dropped (`:189`)
+    uint64_t first = 1, n = 0, p = 1;
+    while (p <= len) {
+        if (n == W) {  // `:413`: the buffer is full before the next slot goes in
+            std::printf("%s\t%llu\t%llu\t0\t0\t0\n", chr.c_str(), (unsigned long long)first, (unsigned long long)(first + W - 1));
+            first += S;
+            n = W - S;
+        }
+        const uint64_t take = std::min<uint64_t>(W - n, len - p + 1);
+        n += take;
+        p += take;
+    }
+    if (n > W - S && n <= W)  // `:424`
+        std::printf("%s\t%llu\t%llu\t0\t0\t0\n", chr.c_str(), (unsigned long long)first, (unsigned long long)(first + n - 1));
 }
 
 // ---- several GPUs (PGT_DEVICES=0,1,...) ------------------------------------------------------------------------
@@ -474,6 +541,10 @@ int main(int argc, char **argv) {
     const double *p1 = nullptr, *p2 = nullptr;
     const int32_t *n1 = nullptr, *n2 = nullptr;
     size_t n_sites = 0;
+    const char *sync_env = std::getenv("PGT_DXY_SYNC");
+    if (sync_env && std::strcmp(sync_env, "reference") && std::strcmp(sync_env, "intersection"))
+        die("PGT_DXY_SYNC must be 'intersection' (the default) or 'reference'");
+    const bool sync_as_reference = sync_env && !std::strcmp(sync_env, "reference");
     const bool same_sites = m1.n == m2.n && m1.runs.name == m2.runs.name && m1.runs.len == m2.runs.len &&
                             std::memcmp(m1.pos.data(), m2.pos.data(), m1.n * sizeof(uint32_t)) == 0;
     const bool on_device = same_sites && m1.on_device && m2.on_device;  // frequencies and counts stay on the GPU
@@ -482,6 +553,31 @@ int main(int argc, char **argv) {
         runs = m1.runs;
         pos = m1.pos.data(); p1 = m1.freq.data(); p2 = m2.freq.data(); n1 = m1.nind.data(); n2 = m2.nind.data();
         n_sites = m1.n;
+    } else if (sync_as_reference) {
+        fetch_columns(m1);
+        fetch_columns(m2);
+        std::string last_chr;
+        const auto pairs = pair_as_the_reference(m1, m2, last_chr);
+        if (pairs.empty()) {  // no site processed at all: the closing code alone (`:407-433`)
+            if (W > 0 && !fixedsite) {
+                auto it = chrsize.find(last_chr);
+                if (it == chrsize.end()) die("Unable to determine size for " + last_chr);  // dxyWindow.cpp:410-413
+                print_placeholder_chromosome(last_chr, it->second, W, S, skip_missing);
+            }
+            std::fprintf(W == 0 ? stdout : stderr, "0\t0\t0\n");
+            finish(timer);
+        }
+        size_t run1 = 0, end1 = m1.runs.len[0];
+        for (const auto &pr : pairs) {  // Pop1's line, Pop2's frequency and count beside it, under Pop1's chromosome name
+            while (pr.first >= end1) end1 += m1.runs.len[++run1];
+            const std::string &chr1 = m1.runs.name[run1];
+            pos_v.push_back(m1.pos[pr.first]);
+            p1_v.push_back(m1.freq[pr.first]); p2_v.push_back(m2.freq[pr.second]);
+            n1_v.push_back(m1.nind[pr.first]); n2_v.push_back(m2.nind[pr.second]);
+            runs.add(chr1.data(), chr1.data() + chr1.size());
+        }
+        pos = pos_v.data(); p1 = p1_v.data(); p2 = p2_v.data(); n1 = n1_v.data(); n2 = n2_v.data();
+        n_sites = pos_v.size();
     } else {
         fetch_columns(m1);
         fetch_columns(m2);

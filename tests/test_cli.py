@@ -26,6 +26,15 @@ def run(cmd, **kw):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=120, **kw)
 
 
+def run_all(jobs, workers=3):
+    """jobs: [(cmd, env or None), ...] -> their results in order, at most `workers` children at a time.  Most of a small CLI
+    run is process and HIP start-up (0.2-0.4 s): the variants of one command (parsers, device lists, cuts) run side by
+    side instead of one after the other — the GPU box allows six processes on the card, this keeps to three + pytest."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(lambda j: run(j[0]) if j[1] is None else run(j[0], env=j[1]), jobs))
+
+
 # ---- CPU: command-line behaviour (fstWindow.cpp:37-67,164-170; dxyWindow.cpp:63-139,537-538) ----
 def test_usage_exits_zero(hosts):
     for tool in ("fstWindow", "hetWindow"):
@@ -117,12 +126,13 @@ def test_failed_output_write_is_not_a_success(hosts, tmp_path):
 def test_fst_het_cli_against_reference_goldens(hosts, tmp_path):
     cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"]
     exact = 0
+    cases = [c for i, c in enumerate(cases) if not (i % 3 and "note" not in c)]  # every third random case keeps the test short
+    jobs = []
     for i, c in enumerate(cases):
-        if i % 3 and "note" not in c:  # every third random case keeps the test short
-            continue
-        f = tmp_path / "in.txt"
+        f = tmp_path / f"in{i}.txt"
         f.write_text(c["input"])
-        r = run([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])])
+        jobs.append(([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], None))
+    for c, r in zip(cases, run_all(jobs)):
         assert r.returncode == 0, r.stderr
         tsv_equal(r.stdout, c["stdout"], 4)
         exact += r.stdout == c["stdout"]
@@ -209,6 +219,79 @@ def test_dxy_cli_hand_walked_cases(hosts, tmp_path, env_extra):
             assert got.returncode == 0, (c["name"], got.stderr)
             assert got.stdout == want_out, (c["name"], r, env_extra, got.stdout)
             assert got.stderr == want_err, (c["name"], r, env_extra, got.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_extra", [{}, {"PGT_GPU_INGEST": "1"}, {"PGT_DEVICES": "0,0"}])
+def test_dxy_cli_reference_sync_mode_prints_what_the_reference_prints(hosts, tmp_path, env_extra):
+    """PGT_DXY_SYNC=reference: the host replays the reference's catch-up loops (dxyWindow.cpp:315-331) instead of intersecting
+    the two site lists.  (1) EVERY hand-walked case — also H4 (Pop2's extra site at a chromosome end ends the run), H6 (a
+    position coincidence pairs sites across chromosomes) and H10 (no shared site: the first chromosome padded with empty
+    windows, `0 0 0`) — prints the bytes the paper walk of the reference gives.  (2) 150 random file pairs (identical, nested
+    either way, non-nested; every mode) against tests/dxy_stream_model.py, the line-by-line restatement of the reference's
+    loop: stdout and stderr equal (the sum column to the printed digits).  The default mode is unchanged
+    (test_dxy_cli_hand_walked_cases)."""
+    import random
+    import dxy_stream_model as model
+    env = dict(os.environ, PGT_DXY_SYNC="reference", **env_extra)
+    k = helpers.load_golden("dxy_hand_walked.json")
+    for c in k["cases"]:
+        m1, m2, sz = helpers.write_hand_walked_case(c, k["header"], tmp_path)
+        for r in c["runs"]:
+            cmd = [hosts["dxyWindow"], "-winsize", str(r["winsize"]), "-stepsize", str(r["stepsize"]), "-minind", str(c["minind"]),
+                   "-fixedsite", str(r["fixedsite"]), "-skip_missing", str(r["skip_missing"])]
+            if not r["fixedsite"]:
+                cmd += ["-sizefile", sz]
+            got = run(cmd + [m1, m2], env=env)
+            assert (got.returncode, got.stdout, got.stderr) == (0, r["stdout"], r["stderr"]), (c["name"], r, got.stdout, got.stderr)
+    bad = run([hosts["dxyWindow"], "-winsize", "2", "-stepsize", "1", "-fixedsite", "1", m1, m2], env=dict(env, PGT_DXY_SYNC="both"))
+    assert bad.returncode == 255 and "PGT_DXY_SYNC" in bad.stderr
+    if env_extra:
+        return  # the random pairs once (host parser, one context): the pairing happens on the host whatever parsed the files
+    rng = random.Random(55)
+    hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd"
+    jobs, want = [], []
+    while len(jobs) < 150:
+        n_chr = rng.randint(1, 4)
+        rows1, rows2, sizes = [], [], {}
+        kind = rng.choice(["same", "pop2_in_pop1", "pop1_in_pop2", "other", "other"])
+        for ci in range(n_chr):
+            L = rng.randint(1, 30)
+            name = f"c{ci}"
+            sizes[name] = L + (rng.randint(0, 3) if rng.random() < 0.3 else 0)
+            for p_ in sorted(rng.sample(range(1, L + 1), rng.randint(1, min(L, 8)))):
+                if kind in ("same", "pop2_in_pop1") or rng.random() < 0.7:
+                    rows1.append((name, p_, round(rng.random(), 6), rng.randint(0, 6)))
+                if kind in ("same", "pop1_in_pop2") or rng.random() < 0.7:
+                    rows2.append((name, p_, round(rng.random(), 6), rng.randint(0, 6)))
+        if not rows1 or not rows2:
+            continue
+        mode = rng.randint(0, 3)
+        W = rng.randint(1, 9)
+        S = rng.randint(1, W)
+        W, S, fixed = (0, 0, 1) if mode == 0 else (W, S, 1 if mode == 1 else 0)
+        minind, skip = rng.randint(1, 4), rng.randint(0, 1)
+        d = tmp_path / f"pair{len(jobs)}"
+        d.mkdir()
+        _write_maf(d / "p1.mafs", hdr, rows1)
+        _write_maf(d / "p2.mafs", hdr, rows2)
+        (d / "sizes.txt").write_text("".join(f"{c_}\t{n_}\n" for c_, n_ in sizes.items()))
+        cmd = [hosts["dxyWindow"], "-winsize", str(W), "-stepsize", str(S), "-minind", str(minind), "-fixedsite", str(fixed), "-skip_missing", str(skip)]
+        jobs.append((cmd + ([] if fixed else ["-sizefile", str(d / "sizes.txt")]) + [str(d / "p1.mafs"), str(d / "p2.mafs")], env))
+        want.append((kind, model.maf2dxy(rows1, rows2, W, S, minind, fixed, sizes, skip)))
+    compared = refused = 0
+    for (cmd, _), (kind, (mrc, mout, merr)), got in zip(jobs, want, run_all(jobs)):
+        if mrc != 0:  # the first chromosomes differ: both refuse
+            assert got.returncode == 255, (cmd, got.stderr)
+            continue
+        if got.returncode == 255 and "increase strictly" in got.stderr:  # a mis-pairing left positions out of order inside a chromosome: the
+            refused += 1                                       # base-pair machine of the product refuses that (INTEGRATION.md 3a)
+            continue
+        assert got.returncode == 0, (cmd, kind, got.stderr)
+        tsv_equal(got.stdout, mout, 3)
+        tsv_equal(got.stderr, merr, 0)
+        compared += 1
+    assert compared >= 130 and refused <= 8, (compared, refused)
 
 
 @pytest.mark.gpu
@@ -341,19 +424,22 @@ def hosts_ext(hosts):
     return {t: os.path.join(BIN, t) for t in ("ihsWindow", "xpehhWindow")}
 
 
+def _extreme_argv(hosts_ext, c, tmp_path, i):
+    """The argv of one ref_extreme.json case, its files written under a directory of its own (the cases run side by side)."""
+    d = tmp_path / f"case{i}"
+    d.mkdir()
+    paths = {}
+    for name, text in c["files"].items():
+        (d / name).write_text(text)
+        paths[name] = str(d / name)
+    return [hosts_ext[c["tool"]]] + [paths[a[1:]] if a.startswith("@") else a for a in c["args"]]
+
+
 @pytest.mark.gpu
 def test_extreme_cli_against_reference_goldens(hosts_ext, tmp_path):
     cases = helpers.load_golden("ref_extreme.json")["cases"]
-    for i, c in enumerate(cases):
-        if i % 2:
-            continue
-        paths = {}
-        for name, text in c["files"].items():
-            p = tmp_path / name
-            p.write_text(text)
-            paths[name] = str(p)
-        argv = [hosts_ext[c["tool"]]] + [paths[a[1:]] if a.startswith("@") else a for a in c["args"]]
-        r = run(argv)
+    cases = cases[::2]
+    for c, r in zip(cases, run_all([(_extreme_argv(hosts_ext, c, tmp_path, i), None) for i, c in enumerate(cases)])):
         assert r.returncode == 0, r.stderr
         assert r.stdout == c["stdout"], c["args"]  # selections and integer ratios: byte-identical
 
@@ -369,14 +455,8 @@ def test_extreme_cli_device_parser_and_several_gpus_print_the_reference_tsv(host
     assert len(cases) >= 100
     if len(env_extra) == 1:  # all 140 cases with both features together, every third with one of them (the suite's time budget)
         cases = cases[::3]
-    for c in cases:
-        paths = {}
-        for name, text in c["files"].items():
-            p = tmp_path / name
-            p.write_text(text)
-            paths[name] = str(p)
-        argv = [hosts_ext[c["tool"]]] + [paths[a[1:]] if a.startswith("@") else a for a in c["args"]]
-        r = run(argv, env=dict(os.environ, **env_extra))
+    env = dict(os.environ, **env_extra)
+    for c, r in zip(cases, run_all([(_extreme_argv(hosts_ext, c, tmp_path, i), env) for i, c in enumerate(cases)])):
         assert r.returncode == 0, (c["args"], r.stderr)
         assert r.stdout == c["stdout"], (c["args"], env_extra)
 
@@ -541,18 +621,21 @@ def test_gpu_ingest_cli_equals_host_parser(hosts, tmp_path):
     (=0): identical stdout, stderr and exit code — reference-made goldens, inputs with irregular numbers,
     CRLF, blank-line stops, no trailing newline, and errors (the message carries the line number)."""
     def both(cmd):
-        a = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1"))
-        b = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="0"))
+        a, b = run_all([(cmd, dict(os.environ, PGT_GPU_INGEST="1")), (cmd, dict(os.environ, PGT_GPU_INGEST="0"))])
         assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), (cmd, a.stderr[-300:], b.stderr[-300:])
         return a
 
     cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::4]
-    for c in cases:
-        f = tmp_path / "in.txt"
+    jobs = []
+    for i, c in enumerate(cases):
+        f = tmp_path / f"in{i}.txt"
         f.write_text(c["input"])
-        r = both([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])])
-        assert r.returncode == 0
-        tsv_equal(r.stdout, c["stdout"], 4)
+        cmd = [hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])]
+        jobs += [(cmd, dict(os.environ, PGT_GPU_INGEST="1")), (cmd, dict(os.environ, PGT_GPU_INGEST="0"))]
+    res = run_all(jobs)
+    for c, a, b in zip(cases, res[0::2], res[1::2]):
+        assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr) and a.returncode == 0, (c["tool"], a.stderr[-300:], b.stderr[-300:])
+        tsv_equal(a.stdout, c["stdout"], 4)
     f = tmp_path / "odd.txt"
     body = ("c1\t1\t0.1\t0.2\nc1 2 -0.000012 0.3\r\nc1\t3\t+0.5\t.5\n  c1 \t 4\t1.\t-.25  extra 7\nc1\t5\t1.5e-05\t1E5\n"
             "c1\t6\t0.1234567890123456789\t123456789012345678\nc2\t7\t1e22\t1e23\nc2\t8\t4.9e-324\t2.2250738585072014e-308\n"
@@ -604,9 +687,9 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
     import synth
 
     def runs(cmd, **env):
-        one = run(cmd, env=dict(os.environ, **env))
-        for devs in ("0,0", "0,0,0"):
-            many = run(cmd, env=dict(os.environ, PGT_DEVICES=devs, **env))
+        lists = ("0,0", "0,0,0")
+        one, *several = run_all([(cmd, dict(os.environ, **env))] + [(cmd, dict(os.environ, PGT_DEVICES=devs, **env)) for devs in lists])
+        for devs, many in zip(lists, several):
             assert (many.returncode, many.stdout, many.stderr) == (one.returncode, one.stdout, one.stderr), (cmd, devs, env, many.stderr[-300:])
         return one
 
@@ -652,9 +735,7 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
     os.unlink(big)
     g = synth.het_column(rng, n)
     bigh = tmp_path / "big.het.txt"
-    with open(bigh, "w") as fh:
-        for lo in range(0, n, 1_000_000):
-            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    oracle.write_het_text(str(bigh), chr_ids, pos, g)
     r = runs([hosts["hetWindow"], str(bigh), "50000", "10000"], PGT_GPU_INGEST="1")
     assert r.returncode == 0 and len(r.stdout.splitlines()) > 360
 
@@ -671,9 +752,9 @@ def test_dxy_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, orac
     import synth
 
     def runs(cmd, **env):
-        one = run(cmd, env=dict(os.environ, **env))
-        for devs in ("0,0", "0,0,0"):
-            many = run(cmd, env=dict(os.environ, PGT_DEVICES=devs, **env))
+        lists = ("0,0", "0,0,0")
+        one, *several = run_all([(cmd, dict(os.environ, **env))] + [(cmd, dict(os.environ, PGT_DEVICES=devs, **env)) for devs in lists])
+        for devs, many in zip(lists, several):
             assert (many.returncode, many.stdout, many.stderr) == (one.returncode, one.stdout, one.stderr), (cmd, devs, env, many.stderr[-300:])
         return one
 
@@ -748,8 +829,9 @@ def test_cli_hybrid_ingest_prints_the_same_tsv(hosts, tmp_path, oracle):
     for c in helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::10]:
         f = tmp_path / "in.txt"
         f.write_text(c["input"])
-        for cut in range(1, len(c["input"]) + 2, max(1, len(c["input"]) // 5)):
-            r = hybrid([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], cut)
+        cuts = list(range(1, len(c["input"]) + 2, max(1, len(c["input"]) // 5)))
+        cmd = [hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])]
+        for cut, r in zip(cuts, run_all([(cmd, dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES=str(cut))) for cut in cuts])):
             assert r.returncode == 0, (cut, r.stderr[-300:])
             tsv_equal(r.stdout, c["stdout"], 4)
     rng = np.random.default_rng(2024)
@@ -763,8 +845,8 @@ def test_cli_hybrid_ingest_prints_the_same_tsv(hosts, tmp_path, oracle):
         cmd = [hosts["fstWindow"], str(big), str(W), str(S)]
         one = run(cmd, env=dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES="0"))
         assert one.returncode == 0 and one.stdout
-        for cut in ((1, 4097, size // 3, size // 2 + 11, size - 40, size, size + 5) if S == 10_000 else (4097, size // 2 + 11, size - 40)):
-            r = hybrid(cmd, cut)
+        cuts = (1, 4097, size // 3, size // 2 + 11, size - 40, size, size + 5) if S == 10_000 else (4097, size // 2 + 11, size - 40)
+        for cut, r in zip(cuts, run_all([(cmd, dict(os.environ, PGT_GPU_INGEST="1", PGT_HYBRID_HOST_BYTES=str(cut))) for cut in cuts])):
             assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, cut, r.stderr[-300:])
     timed = hybrid([hosts["fstWindow"], str(big), "50000", "10000"], size // 2, PGT_HOST_TIMING="1")
     assert "head on the host" in timed.stderr and "columns joined" in timed.stderr
@@ -784,9 +866,7 @@ def test_cli_hybrid_ingest_prints_the_same_tsv(hosts, tmp_path, oracle):
     os.unlink(big)
     g = synth.het_column(rng, n)
     bigh = tmp_path / "big.het.txt"
-    with open(bigh, "w") as fh:
-        for lo in range(0, n, 1_000_000):
-            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    oracle.write_het_text(str(bigh), chr_ids, pos, g)
     size = os.path.getsize(bigh)
     for W, S in ((50_000, 10_000), (200_000, 64)):
         cmd = [hosts["hetWindow"], str(bigh), str(W), str(S)]
@@ -879,10 +959,13 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     def passes(cmd, limit, **env):
         return run(cmd, env=dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit), **env))
 
-    for c in helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::3]:
-        f = tmp_path / "in.txt"
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::3]
+    jobs = []
+    for i, c in enumerate(cases):
+        f = tmp_path / f"in{i}.txt"
         f.write_text(c["input"])
-        r = passes([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], 1)
+        jobs.append(([hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])], dict(os.environ, PGT_MAX_RESIDENT_SITES="1")))
+    for c, r in zip(cases, run_all(jobs)):
         assert r.returncode == 0, r.stderr[-300:]
         tsv_equal(r.stdout, c["stdout"], 4)
     import hashlib
@@ -913,13 +996,13 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
         timed = passes(cmd, 300_000, PGT_HOST_TIMING="1")  # the phases say which path ran
         assert "scan runs" in timed.stderr and "passes" in timed.stderr and timed.stdout == one.stdout
         assert "scan runs" not in run(cmd, env=dict(os.environ, PGT_HOST_TIMING="1")).stderr
-        for limit in ((1, 300_000, 1_000_000, 2_999_999, 10**9) if S == 10_000 else (1, 1_000_000)):  # (tests/ingest_fuzz.py draws more)
-            r = passes(cmd, limit)
-            assert (r.returncode, r.stderr) == (0, one.stderr), (W, S, limit, r.stderr[-300:])
-            assert r.stdout == one.stdout, (W, S, limit)
-        for devs in (("0,0", "0,0,0") if S == 10_000 else ("0,0,0",)):  # the blocks go round several contexts and are printed in order
-            r = passes(cmd, 300_000, PGT_DEVICES=devs)
-            assert (r.returncode, r.stdout, r.stderr) == (0, one.stdout, one.stderr), (W, S, devs, r.stderr[-300:])
+        limits = (1, 300_000, 1_000_000, 2_999_999, 10**9) if S == 10_000 else (1, 1_000_000)  # (tests/ingest_fuzz.py draws more)
+        lists = ("0,0", "0,0,0") if S == 10_000 else ("0,0,0",)  # the blocks go round several contexts and are printed in order
+        res = run_all([(cmd, dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))) for limit in limits] +
+                      [(cmd, dict(os.environ, PGT_MAX_RESIDENT_SITES="300000", PGT_DEVICES=devs)) for devs in lists])
+        for what, r in zip(limits + lists, res):
+            assert (r.returncode, r.stderr) == (0, one.stderr), (W, S, what, r.stderr[-300:])
+            assert r.stdout == one.stdout, (W, S, what)
     # no window at all (every run shorter than the window), and a bad line: still an error, as in the resident run
     short = tmp_path / "short.fst.txt"
     short.write_text("".join(f"c{1 + i // 50}\t{i + 1}\t0.01\t0.2\n" for i in range(200)))
@@ -949,9 +1032,7 @@ def test_cli_in_passes_prints_the_resident_tsv(hosts, tmp_path, oracle):
     os.unlink(big)
     g = synth.het_column(rng, n)
     bigh = tmp_path / "big.het.txt"
-    with open(bigh, "w") as fh:
-        for lo in range(0, n, 1_000_000):
-            fh.write("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids[lo: lo + 1_000_000], pos[lo: lo + 1_000_000], g[lo: lo + 1_000_000])))
+    oracle.write_het_text(str(bigh), chr_ids, pos, g)
     for W, S in ((50_000, 10_000), (200_000, 64), (1000, 1000)):
         cmd = [hosts["hetWindow"], str(bigh), str(W), str(S)]
         one = run(cmd)
@@ -1040,11 +1121,14 @@ def test_cli_device_window_table_equals_host_table(hosts, tmp_path, oracle):
     import synth
     on, off = dict(os.environ, PGT_DEVICE_WINTAB="1"), dict(os.environ, PGT_DEVICE_WINTAB="0")
     cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::4]
-    for c in cases:
-        f = tmp_path / "in.txt"
+    jobs = []
+    for i, c in enumerate(cases):
+        f = tmp_path / f"in{i}.txt"
         f.write_text(c["input"])
         cmd = [hosts[c["tool"]], str(f), str(c["W"]), str(c["S"])]
-        a, b = run(cmd, env=on), run(cmd, env=off)
+        jobs += [(cmd, on), (cmd, off)]
+    res = run_all(jobs)
+    for c, a, b in zip(cases, res[0::2], res[1::2]):
         assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (c["tool"], c["W"], c["S"])
         tsv_equal(a.stdout, c["stdout"], 4)
     k = helpers.load_golden("dxy_kat.json")
