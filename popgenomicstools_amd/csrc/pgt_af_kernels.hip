@@ -166,6 +166,10 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     for (uint64_t t = wave0; t < n_l2; t += n_waves) {
         const uint64_t base = t * kTile2;
         const bool full = base + kTile2 <= n;
+        // WAVES START THEIR TILES AT DIFFERENT PIECES (round 5; pgt_kernels.hip: tile_rotation): the waves run in lockstep, and
+        // without this all of them are at the same offset of their tiles at any moment.  Even, a multiple of the burst; the
+        // partial last tile is walked from its start (its guarded loads stop at n).
+        const int rot = full ? (int)(((wave0 * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - (BURST > 0 ? BURST : 4))) : 0;
         double l2acc = 0.0;
         double2 cur[NP];
         auto load_tile = [&](double2 *dst, int j) {
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
         if constexpr (BURST > 0) {
             if (full) {
 #pragma unroll 1
-                for (int j0 = 0; j0 < kRadix; j0 += BURST) {
+                for (int i0 = 0; i0 < kRadix; i0 += BURST) {
+                    const int j0 = (i0 + rot) & (kRadix - 1);  // the walk starts at a piece of the wave's own (see `rot`)
                     double2 d[NP][BURST];
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
@@ -209,22 +214,20 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
                         af_accumulate<NP>(vals, fy);
                         if ((u & (kAfPieces - 1)) == kAfPieces - 1) {
                             rs_steps<V, 0>(vals, lane);
-                            if (my >= 0) {
-                                stage[(j / kAfPieces) * V + my] = vals[0];
-                                l2acc += vals[0];
-                            }
+                            if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];
                         }
                     }
                 }
             }
         }
         if (BURST == 0 || !full) {
-        load_tile(cur, 0);
+        load_tile(cur, rot);
 #pragma unroll kAfPieces
-        for (int j = 0; j < kRadix; ++j) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
+        for (int i = 0; i < kRadix; ++i) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
+            const int j = (i + rot) & (kRadix - 1);  // rot is even: i and j have the same parity, a leaf's two pieces stay together
             double2 nxt[NP];
-            if (j + 1 < kRadix) load_tile(nxt, j + 1);  // next piece's loads fly while this one is reduced
-            if ((j & (kAfPieces - 1)) == 0) {
+            if (i + 1 < kRadix) load_tile(nxt, (j + 1) & (kRadix - 1));  // next piece's loads fly while this one is reduced
+            if ((i & (kAfPieces - 1)) == 0) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) vals[v] = 0.0;
             }
@@ -233,18 +236,21 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
             af_accumulate<NP>(vals, fx);
             af_accumulate<NP>(vals, fy);
-            if ((j & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
+            if ((i & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
                 rs_steps<V, 0>(vals, lane);
-                if (my >= 0) {
-                    stage[(j / kAfPieces) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
-                    l2acc += vals[0];
-                }
+                if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
         }
         }
-        if (my >= 0) *af_node<V>(tv, 1, my, t) = l2acc;  // the level-2 node: V consecutive doubles, one 8*V-byte run
+        // the level-2 node = the 32 leaf nodes added in LEAF order, whatever order they were produced in (they were added as
+        // produced until round 5: now the walk starts somewhere else in every wave, and the node must not depend on the wave)
+        if (my >= 0) {
+#pragma unroll 8
+            for (int q = 0; q < kAfRadix1; ++q) l2acc += stage[q * V + my];
+            *af_node<V>(tv, 1, my, t) = l2acc;  // V consecutive doubles, one 8*V-byte run
+        }
         // the tile's 64 level-1 nodes = ONE contiguous block of 512*V bytes, written as 1-KiB wave stores
         // (the stage belongs to this wave alone, LDS operations of a wave complete in order: no barrier)
         {

@@ -159,11 +159,29 @@ struct NodeStage {
         if (++held == STAGE) flush();
     }
 };
-// 64 KiB of one column of a level-2 tile -> the 64 leaf sums, lane j keeps leaf j's; U loads in flight per lane
+// WAVES START THEIR TILES AT DIFFERENT LEAVES (round 5).  All waves of a launch run in near lockstep (that is what makes the
+// deferred node stores land together), so without this every wave is at the SAME offset of its 64-KiB tile at any moment:
+// the chip's ~2000 outstanding 4-KiB requests all have the same address bits 12-15, and whatever part of the HBM channel /
+// bank selection those bits feed is hit by all of them at once.  Each wave therefore walks its tile from a leaf of its own
+// — a hash of the wave index, in steps of the batch size — and wraps around; a leaf's sum does not depend on when it is read
+// and lane j still keeps leaf j's, so every node is bit for bit what it was.  Interleaved A/B of the two builds in one
+// process (tools/lib_ab.py; profiles/r05/lib_ab_rot*.md; % of the HBM peak, fst build): 10^8 sites 81.3 -> 84.9, 79.5 -> 82.9;
+// 10^9 sites 83.2 -> 85.7, 80.3 -> 81.4.  A plain (4 x wave) & 63 gives the same at 10^8 sites and a point less at 10^9, a
+// start that changes from tile to tile (hash of the tile index) or differs between the two columns of a tile gains less;
+// starts at any leaf (steps of 1 or 2 leaves, the batch wrapping inside) lose a point at 10^8 sites and gain half a point at
+// 10^9; other hashes tie.  The dxy, fused and extreme-score builds walk their tiles the same way: dxy 77.5 -> 82.2 % at 10^8
+// sites, 83.6 -> 85.4 at 10^9; fused 79.2 -> 82.1, 82.6 -> 83.7; extreme score unchanged (lib_ab_rotation_all_*.md).
 template <int U>
-__device__ __forceinline__ void fst_column_sums(const double2 *__restrict__ p, int lane, double &keep) {
+__device__ __forceinline__ int tile_rotation(uint64_t wave) {
+    return (int)(((wave * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - U));  // a multiple of U below 64 (U a power of two)
+}
+// 64 KiB of one column of a level-2 tile -> the 64 leaf sums, lane j keeps leaf j's; U loads in flight per lane; the walk
+// starts at leaf `rot` (a multiple of U) and wraps
+template <int U>
+__device__ __forceinline__ void fst_column_sums(const double2 *__restrict__ p, int lane, double &keep, int rot = 0) {
 #pragma unroll 1
-    for (int j = 0; j < kRadix; j += U) {
+    for (int j0 = 0; j0 < kRadix; j0 += U) {
+        const int j = (j0 + rot) & (kRadix - 1);
         double2 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] = load16<true>(p + (j + u) * kWave + lane);
@@ -197,10 +215,11 @@ __global__ __launch_bounds__(256) void fst_build_kernel(PairCols cols, uint64_t 
             const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(a + base);
             const double2 *__restrict__ pb = reinterpret_cast<const double2 *>(b + base);
             const bool last = TAIL_SCOPE != 0 && t + n_waves >= n_l2;  // wave-uniform: this wave's last tile
+            const int rot = tile_rotation<UNROLL>(wave0);
             if (TAIL_SCOPE == 2 && last) fst_column_sums<TAIL_UNROLL>(pa, lane, keep_a);
-            else fst_column_sums<UNROLL>(pa, lane, keep_a);  // the tile's 64 KiB of `a` ...
+            else fst_column_sums<UNROLL>(pa, lane, keep_a, rot);  // the tile's 64 KiB of `a` ...
             if (TAIL_SCOPE != 0 && last) fst_column_sums<TAIL_UNROLL>(pb, lane, keep_b);
-            else fst_column_sums<UNROLL>(pb, lane, keep_b);  // ... then its 64 KiB of `b`
+            else fst_column_sums<UNROLL>(pb, lane, keep_b, rot);  // ... then its 64 KiB of `b`
         } else {
             for (int j = 0; j < kRadix; ++j) {
                 const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
@@ -378,8 +397,10 @@ __device__ __forceinline__ void dxy_build_body(const double *__restrict__ p1, co
             const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(p2 + base);
             const int4 *__restrict__ m1 = reinterpret_cast<const int4 *>(n1 + base);  // base is a multiple of 8192: 16-byte aligned
             const int4 *__restrict__ m2 = reinterpret_cast<const int4 *>(n2 + base);
+            const int rot = tile_rotation<U>(wave0);  // see fst_column_sums: the walk over the tile starts at a leaf of the wave's own
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += U) {
+            for (int j0 = 0; j0 < kRadix; j0 += U) {
+                const int j = (j0 + rot) & (kRadix - 1);
                 double2 x1[U], x2[U];
                 int4 k1[U / 2], k2[U / 2];  // one 16-byte load per lane and PAIR of leaf tiles
 #pragma unroll
@@ -513,15 +534,17 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
             const int4 *__restrict__ m2 = reinterpret_cast<const int4 *>(f.n2 + base);
             const uint4 *__restrict__ h0 = reinterpret_cast<const uint4 *>(f.g[0] + base);
             const uint4 *__restrict__ h1 = reinterpret_cast<const uint4 *>(f.g[1] + base);
+            const int rot = tile_rotation<U>(wave0);  // see fst_column_sums (the genotype bursts keep their places in the walk)
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += U) {
+            for (int j0 = 0; j0 < kRadix; j0 += U) {
+                const int j = (j0 + rot) & (kRadix - 1);
                 double2 x1[U], x2[U];
                 int4 k1[U / 2], k2[U / 2];
                 uint4 gb[kHetChunk];
-                const bool burst = j == 0 || j == kRadix / 2;  // wave-uniform: genotype column 0 / 1
+                const bool burst = j0 == 0 || j0 == kRadix / 2;  // wave-uniform: genotype column 0 / 1
                 if (burst) {  // the genotype column's 8 KiB: a burst of its own, awaited
 #pragma unroll
-                    for (int u = 0; u < kHetChunk; ++u) gb[u] = load16_nt((j == 0 ? h0 : h1) + u * kWave + lane);
+                    for (int u = 0; u < kHetChunk; ++u) gb[u] = load16_nt((j0 == 0 ? h0 : h1) + u * kWave + lane);
                     load_fence((int)gb[kHetChunk - 1].w);
                 }
                 // the dxy columns one at a time, as in dxy_build_body
@@ -547,7 +570,7 @@ __global__ __launch_bounds__(256) void dxy_het_build_kernel(DxyHetBuildArgs f) {
 #pragma unroll
                     for (int u = 0; u < kHetChunk; ++u) {
                         const uint32_t c = wave_sum(het_count_packed(gb[u]));  // both fields <= 1024: no carry between them
-                        if (lane == (j == 0 ? 0 : kHetChunk) + u) hkeep = c;
+                        if (lane == (j0 == 0 ? 0 : kHetChunk) + u) hkeep = c;
                     }
                 }
             }
@@ -846,8 +869,10 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t
         NodeExt keep = node_identity<NodeExt>();
         if (base + kTile2 <= n) {
             const double2 *__restrict__ ps = reinterpret_cast<const double2 *>(g.s + base);
+            const int rot = tile_rotation<UNROLL>(wave0);  // see fst_column_sums
 #pragma unroll 1
-            for (int j = 0; j < kRadix; j += UNROLL) {
+            for (int j0 = 0; j0 < kRadix; j0 += UNROLL) {
+                const int j = (j0 + rot) & (kRadix - 1);
                 double2 v[UNROLL][2];  // leaf tile = 256 sites = two 1-KiB wave loads; 2*UNROLL loads in flight per lane
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)

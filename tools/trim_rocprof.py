@@ -11,7 +11,12 @@ kept), plus per-kernel summary rows (avg/min/max) — the inputs of roofline.tra
 stats: the rocprofv3 --stats summary with torch's kernels dropped except the five largest.
 headline <trimmed pmc_counters.csv> <round> <command>: profiles/pmc_headline.json on stdout — the build kernel's average
     FETCH_SIZE / WRITE_SIZE per dispatch, the HBM bytes per launch they give and the SHA-256 of the kernel sources they
-    were measured on (bench.py reports roofline.traffic from it only while that hash is the tree's)."""
+    were measured on (bench.py reports roofline.traffic from it only while that hash is the tree's).
+timeline <..._kernel_trace.csv>: the library's kernels in launch order with their durations and the idle gap in front of each
+    (end of the previous kernel of the process -> start of this one), then per kernel name the median duration and median gap:
+    what a step costs beyond its build kernel (query, tree_up, launch gaps).
+traffic <trimmed pmc csv> <sites>: per build kernel HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) against the algorithmic bytes,
+    and the SQ wave-cycle split (waiting on memory / issue stalls / executing), as a markdown table."""
 import csv
 import glob
 import os
@@ -81,7 +86,77 @@ def headline(trimmed, rnd, command):
     print()
 
 
+def timeline(f):
+    rows = [r for r in csv.DictReader(open(f))]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    prev_end = None
+    per = defaultdict(lambda: ([], []))
+    print("| # | kernel | grid | start us | duration us | gap before us |\n|---|---|---|---|---|---|")
+    t0 = None
+    shown = 0
+    for r in rows:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        name = r["Kernel_Name"]
+        mine = "pgt::" in name
+        if mine:
+            k = short(name)
+            if t0 is None:
+                t0 = st
+            gap = (st - prev_end) / 1e3 if prev_end is not None else float("nan")
+            per[k][0].append((en - st) / 1e3)
+            if prev_end is not None:
+                per[k][1].append(gap)
+            if shown < 400:
+                print(f"| {shown} | {k[:60]} | {r.get('Grid_Size', '')} | {(st - t0) / 1e3:.1f} | {(en - st) / 1e3:.1f} | {gap:.1f} |")
+                shown += 1
+        prev_end = en
+    import statistics
+    print("\n| kernel | launches | median duration us | median gap before us |\n|---|---|---|---|")
+    for k, (d, g) in per.items():
+        print(f"| {k[:70]} | {len(d)} | {statistics.median(d):.1f} | {statistics.median(g) if g else float('nan'):.1f} |")
+
+
+ALG_BYTES_PER_SITE = {"fst_build_kernel": 16, "dxy_build_kernel": 24, "het_build_kernel_w4": 1, "het_build_kernel": 1, "dxy_het_build_kernel": 26,
+                      "af_build_kernel<8": 64, "af_build_kernel<2": 16, "ext_build_kernel": 8}
+
+
+def traffic(trimmed, sites):
+    n = float(sites)
+    d = defaultdict(dict)
+    for r in csv.reader(open(trimmed)):
+        if len(r) >= 8 and r[0] == "summary" and "build" in r[1]:
+            d[(r[1], r[2])][r[3]] = float(r[5])
+    print(f"{n:.0e} sites; HBM bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (every byte of every build kernel is read by a 16-byte load, the "
+          "width the x2 is calibrated for); SQ columns: shares of SQ_WAVE_CYCLES\n")
+    print("| kernel | grid | algorithmic GB | fetched GB | written GB | traffic / algorithmic | waiting (SQ_WAIT_ANY) | issue stalls (SQ_WAIT_INST_ANY) | "
+          "executing (SQ_ACTIVE_INST_ANY) | of which VALU | VALU issue share of the SIMDs | L2 hit rate |\n|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for (k, g), c in sorted(d.items()):
+        base = next((b for key, b in ALG_BYTES_PER_SITE.items() if k.startswith(key)), None)
+        if base is None or "FETCH_SIZE" not in c:
+            continue
+        pairs = 1
+        if k.startswith("fst_build_kernel") and int(g) > 200000:  # grid.y = pairs: pmc_kernels.py batches 6
+            pairs = round(int(g) / 130304) if n == 1e8 else 6
+        alg = base * n * pairs
+        fetched, written = 2 * c["FETCH_SIZE"] * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+        wc = c.get("SQ_WAVE_CYCLES", 0.0)
+        def share(x):
+            return f"{c[x] / wc * 100:.1f} %" if wc and x in c else "-"
+        simd = "-"
+        if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+            simd = f"{c['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.0f} %"
+        hit = f"{c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']) * 100:.1f} %" if "TCC_HIT_sum" in c else "-"
+        print(f"| {k[:44]} | {g} | {alg / 1e9:.3f} | {fetched / 1e9:.3f} | {written / 1e9:.3f} | **{(fetched + written) / alg:.3f}** | {share('SQ_WAIT_ANY')} | "
+              f"{share('SQ_WAIT_INST_ANY')} | {share('SQ_ACTIVE_INST_ANY')} | {share('SQ_ACTIVE_INST_VALU')} | {simd} | {hit} |")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2])
+        sys.exit(0)
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if sys.argv[1] == "headline":
         headline(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
