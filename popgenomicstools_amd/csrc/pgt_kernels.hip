@@ -717,6 +717,37 @@ struct HetTraits {
             }
         }
     }
+    // The two ragged ends of a window, [l0,l1) and [r0,r1), each shorter than a leaf: one 16-byte load per lane and side, BOTH
+    // requested before either is counted (the counts are integers: the order of the additions is immaterial).  A side that
+    // needs a second block per lane (it starts late in its first 16 bytes) or whose last block would reach beyond the
+    // column takes sum_sites; the decision is wave-uniform.
+    static __device__ __forceinline__ void sum_two_ranges(Node &acc, const Cols &c, uint64_t l0, uint64_t l1, uint64_t r0,
+                                                          uint64_t r1, int lane, uint64_t n_sites) {
+        const uint64_t lbase = l0 & ~15ull, rbase = r0 & ~15ull;
+        const bool simple = ((l1 + 15) & ~15ull) <= n_sites && ((r1 + 15) & ~15ull) <= n_sites &&
+                            l1 - lbase <= 16ull * kWave && r1 - rbase <= 16ull * kWave;
+        if (!simple) {
+            sum_sites(acc, c, l0, l1, lane, n_sites);
+            sum_sites(acc, c, r0, r1, lane, n_sites);
+            return;
+        }
+        const uint64_t lb = lbase + 16ull * lane, rb = rbase + 16ull * lane;
+        const bool inl = l0 < l1 && lb < l1, inr = r0 < r1 && rb < r1;
+        const uint4 missing{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+        const uint4 wl = inl ? *reinterpret_cast<const uint4 *>(c + lb) : missing;
+        const uint4 wr = inr ? *reinterpret_cast<const uint4 *>(c + rb) : missing;
+        auto count = [&](const uint4 &w, bool in, uint64_t from, uint64_t to, uint64_t base) {
+            const int64_t l = in ? (int64_t)from - (int64_t)base : 0, h = in ? (int64_t)to - (int64_t)base : 0;
+            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t m = byte_mask(l - 4 * j, h - 4 * j);
+                het_count_word((wd[j] & m) | (~m & 0x80808080u), acc.nonmiss, acc.nhet);
+            }
+        };
+        count(wl, inl, l0, l1, lb);
+        count(wr, inr, r0, r1, rb);
+    }
     static __device__ __forceinline__ void finish(Row *out, const Node &t, uint32_t start, uint32_t end,
                                                   uint64_t, uint64_t, const Cols &, const uint32_t *) {
         Row r;
@@ -1020,6 +1051,72 @@ __device__ __forceinline__ typename Tr::Node total_partial(const char *tree, con
     return acc;
 }
 
+// THE COMMON DESCENT WITH ALL ITS LOADS UP FRONT (round 5).  range_partial asks for one level's ragged nodes, adds them, and
+// only then works out the next level: three dependent round trips per window, and the per-window query is a chain of round
+// trips — at 10^4 windows (10^8 sites, the 8-GPU shard) there is about one window per resident wave and the kernel's time IS
+// that chain.  For the shape nearly every window of a table has — the tree built to exactly two levels (pgt_set_max_window
+// below a level-3 node), the window spanning at least one whole level-2 node and at most 64 of them — every address follows
+// from (lo, hi) alone, so the ragged sites, the ragged level-1 nodes and the level-2 run are all requested before the first
+// addition.  The additions are range_partial's, in its order (sites left / right, level-1 left / right, level 2; a masked
+// slot adds the identity, which changes no bit: the accumulator starts at +0.0 and can never be -0.0): rows unchanged.
+// Any other shape returns false and takes range_partial.  (Round 2 had planned the WHOLE descent for any depth in scalar
+// registers: 27 more VGPRs, slower at 10^5 windows, profiles/r02/measure_query_pipelined.md; this form has no plan to keep.)
+template <class Tr>
+__device__ __forceinline__ bool range_partial_two_levels(typename Tr::Node &out, const typename Tr::Cols &c, const char *tree,
+                                                         const TreeView &tv, uint64_t lo, uint64_t hi, int lane, uint64_t n_sites) {
+    using Node = typename Tr::Node;
+    if constexpr (Tr::kLeaf == kLeafI8) {
+        // the int8 tree built to ONE level (windows shorter than a 65536-site level-2 node): the level-1 run [a1, b1) is requested
+        // first, then the two ragged ends together (HetTraits::sum_two_ranges); integer counts, any order
+        constexpr uint64_t kLeaf = (uint64_t)Tr::kLeaf;
+        if (tv.n_levels != 1) return false;
+        const uint64_t a1 = (lo + kLeaf - 1) / kLeaf, b1 = hi / kLeaf;
+        if (a1 >= b1 || b1 - a1 > (uint64_t)kWave) return false;
+        const Node *__restrict__ n1 = reinterpret_cast<const Node *>(tree + tv.off[0]);
+        const uint64_t it = a1 + lane;
+        const Node vt = n1[it < b1 ? it : 0];
+        Node acc = node_identity<Node>();
+        Tr::sum_two_ranges(acc, c, lo, a1 * kLeaf, b1 * kLeaf, hi, lane, n_sites);
+        node_add(acc, it < b1 ? vt : node_identity<Node>());
+        out = acc;
+        return true;
+    } else if constexpr (Tr::kLeaf != kLeafF64) {
+        return false;  // the extreme-score tree (256-site leaves: four slots a side) keeps range_partial: the front-loaded form needs 66 VGPRs there
+    } else {
+        constexpr uint64_t kLeaf = (uint64_t)Tr::kLeaf;
+        constexpr int kSlots = Tr::kLeaf / kWave;
+        if (tv.n_levels != 2) return false;
+        const uint64_t a1 = (lo + kLeaf - 1) / kLeaf, b1 = hi / kLeaf;  // whole level-1 nodes [a1, b1)
+        if (a1 >= b1) return false;
+        const uint64_t a2 = (a1 + kRadix - 1) / kRadix, b2 = b1 / kRadix;  // whole level-2 nodes [a2, b2)
+        if (a2 >= b2 || b2 - a2 > (uint64_t)kWave) return false;
+        const Node none = node_identity<Node>();
+        const Node *__restrict__ n1 = reinterpret_cast<const Node *>(tree + tv.off[0]);
+        const Node *__restrict__ n2 = reinterpret_cast<const Node *>(tree + tv.off[1]);
+        // requests: sites [lo, a1 * leaf) and [b1 * leaf, hi); level-1 nodes [a1, a2 * 64) and [b2 * 64, b1); level-2 nodes [a2, b2)
+        const uint64_t l0 = lo, l1 = a1 * kLeaf, r0 = b1 * kLeaf, r1 = hi, last = n_sites - 1;
+        Node v[2 * kSlots];
+#pragma unroll
+        for (int u = 0; u < 2 * kSlots; ++u) {
+            const uint64_t i = (u < kSlots ? l0 : r0) + lane + (uint64_t)(u % kSlots) * kWave;
+            v[u] = Tr::leaf(c, i < (u < kSlots ? l1 : r1) ? i : last);
+        }
+        const uint64_t il = a1 + lane, ir = b2 * kRadix + lane, it = a2 + lane;
+        const Node vl = n1[il < a2 * kRadix ? il : 0], vr = n1[ir < b1 ? ir : 0], vt = n2[it < b2 ? it : 0];  // node 0 always exists
+        Node acc = none;
+#pragma unroll
+        for (int u = 0; u < 2 * kSlots; ++u) {
+            const uint64_t i = (u < kSlots ? l0 : r0) + lane + (uint64_t)(u % kSlots) * kWave;
+            node_add(acc, i < (u < kSlots ? l1 : r1) ? v[u] : none);
+        }
+        node_add(acc, il < a2 * kRadix ? vl : none);
+        node_add(acc, ir < b1 ? vr : none);
+        node_add(acc, it < b2 ? vt : none);
+        out = acc;
+        return true;
+    }
+}
+
 template <class Tr>
 __device__ __forceinline__ void query_body(const typename Tr::Args &args, const uint32_t *__restrict__ pos,
                                            const TreeView &tv, const pgt_win *__restrict__ win, uint64_t n_win,
@@ -1055,7 +1152,10 @@ __device__ __forceinline__ void query_body(const typename Tr::Args &args, const 
             start = hi > lo ? pos[lo] : 0u;
             end = hi > lo ? pos[hi - 1] : 0u;
         }
-        const typename Tr::Node acc = node_wave_sum(range_partial<Tr>(c, tree, tv, lo, hi, lane, n_sites));
+        typename Tr::Node part;
+        if (!range_partial_two_levels<Tr>(part, c, tree, tv, lo, hi, lane, n_sites))  // wave-uniform
+            part = range_partial<Tr>(c, tree, tv, lo, hi, lane, n_sites);
+        const typename Tr::Node acc = node_wave_sum(part);
         if (lane == 0) Tr::finish(out + (uint64_t)pair * n_win + w, acc, start, end, lo, hi, c, pos);
     }
 }
