@@ -120,7 +120,6 @@ constexpr int kFstStage = 16;                         // tiles staged per wave: 
 constexpr unsigned kFstBuildBlocks = 512;             // 64 KiB of LDS per workgroup -> 2 per CU, 8 waves per CU
 static_assert(kFstBuildBlocks * 4 == kMaxBuildWaves, "the dxy tree reserves one partial sum per build wave");
 constexpr size_t kFstStageBytes = (size_t)4 * kFstStage * 1024;
-constexpr uint64_t kFstSmallTiles = 40000;            // level-2 tiles (3.3e8 sites) up to which 16 loads per lane are kept in flight
 
 // The per-wave LDS stage shared by the fst, dxy and extreme-score builds (16-byte nodes: 1 KiB per row).
 template <class Node>
@@ -885,6 +884,8 @@ __device__ __forceinline__ NodeExt ext_leaf_tile(const double (&k)[4], bool (&va
 }
 
 constexpr int kExtStage = 16;  // tiles staged per wave (16 KiB of LDS): 64 KiB per workgroup -> 2 per CU, as the fst build
+constexpr int kExtStageSmall = 8;  // short inputs: 8 KiB per wave, 32 KiB per workgroup -> 4 per CU = 16 waves (ext_build_launch)
+constexpr uint64_t kExtSmallTiles = 20000;  // level-2 tiles of 16384 sites (3.3e8 sites) up to which an input counts as short
 template <int STAGE = kExtStage, int UNROLL = 4, bool DEFER = true>
 __global__ __launch_bounds__(256) void ext_build_kernel(ExtBuildArgs g, uint64_t n, uint64_t n_l2, TreeView tv) {
     extern __shared__ __attribute__((aligned(16))) char lds_stage[];
@@ -1786,7 +1787,7 @@ int launch_windows_from_plan(const RunPlan *d_plan, uint64_t n_runs, uint64_t n_
 int init_kernels(std::string *err) {  // per pgt_open, i.e. per device: function attributes are per device
     const void *staged[] = {reinterpret_cast<const void *>(fst_build_kernel<>),
                             reinterpret_cast<const void *>(dxy_build_kernel),
-                            reinterpret_cast<const void *>(ext_build_kernel<>), reinterpret_cast<const void *>(ext_build_kernel<kExtStage, 8, true>)};
+                            reinterpret_cast<const void *>(ext_build_kernel<>), reinterpret_cast<const void *>(ext_build_kernel<kExtStageSmall, 2, true>)};
     for (const void *k : staged)
         if (int rc = hip_fail(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFstStageBytes),
                               "hipFuncSetAttribute", err))
@@ -1937,8 +1938,15 @@ void launch_ext_variant(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64
     hipLaunchKernelGGL((ext_build_kernel<STAGE, UNROLL, DEFER>), dim3(build_grid(n_l2, cap)), dim3(256), lds, s, g, n, n_l2, tv);
 }
 void ext_build_launch(hipStream_t s, const ExtBuildArgs &g, uint64_t n, uint64_t n_l2, const TreeView &tv) {
-    if (n_l2 <= kFstSmallTiles / 2)  // 16 loads in flight per lane for short inputs (see fst_build_launch); ext tiles are 16384 sites
-        launch_ext_variant<kExtStage, 8, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
+    // Short inputs (up to 20000 tiles of 16384 sites = 3.3e8 sites): 16 waves per CU with 4 loads in flight each (two leaf tiles
+    // per batch, an 8-KiB stage per wave, 1024 workgroups) — a tile is 128 KiB here, so 8 waves per CU leave a wave only 3
+    // tiles at 10^8 sites and the launch is over before the stream is steady.  Round 5, with the tiles walked from a start of
+    // the wave's own (tile_rotation), interleaved against the round-4 choice (8 waves x 16 loads): 5e7 sites +9.6 %, 10^8
+    // +13.8 % (67.4 -> 76.8 % of the HBM peak), 1.25e8 -1.0 %, 2.5e8 +8.1 %; from 5e8 sites on 8 waves x 8 loads stay ahead
+    // (10^9: 84.7 % against 81.8).  profiles/r05/build_ab_ext_geometry_with_rotation.md; round 4 had measured -12 % at 1.25e8
+    // sites for the same geometry without the rotation.
+    if (n_l2 <= kExtSmallTiles)
+        launch_ext_variant<kExtStageSmall, 2, true>(s, g, n, n_l2, tv, 2 * kFstBuildBlocks);
     else
         launch_ext_variant<kExtStage, 4, true>(s, g, n, n_l2, tv, kFstBuildBlocks);
 }
