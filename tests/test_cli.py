@@ -227,7 +227,7 @@ def test_dxy_cli_reference_sync_mode_prints_what_the_reference_prints(hosts, tmp
     """PGT_DXY_SYNC=reference: the host replays the reference's catch-up loops (dxyWindow.cpp:315-331) instead of intersecting
     the two site lists.  (1) EVERY hand-walked case — also H4 (Pop2's extra site at a chromosome end ends the run), H6 (a
     position coincidence pairs sites across chromosomes) and H10 (no shared site: the first chromosome padded with empty
-    windows, `0 0 0`) — prints the bytes the paper walk of the reference gives.  (2) 150 random file pairs (identical, nested
+    windows, `0 0 0`) — prints the bytes the paper walk of the reference gives.  (2) 100 random file pairs (identical, nested
     either way, non-nested; every mode) against tests/dxy_stream_model.py, the line-by-line restatement of the reference's
     loop: stdout and stderr equal (the sum column to the printed digits).  The default mode is unchanged
     (test_dxy_cli_hand_walked_cases)."""
@@ -251,7 +251,7 @@ def test_dxy_cli_reference_sync_mode_prints_what_the_reference_prints(hosts, tmp
     rng = random.Random(55)
     hdr = "chromo\tposition\tmajor\tminor\tref\tknownEM\tnInd"
     jobs, want = [], []
-    while len(jobs) < 150:
+    while len(jobs) < 100:
         n_chr = rng.randint(1, 4)
         rows1, rows2, sizes = [], [], {}
         kind = rng.choice(["same", "pop2_in_pop1", "pop1_in_pop2", "other", "other"])
@@ -291,7 +291,7 @@ def test_dxy_cli_reference_sync_mode_prints_what_the_reference_prints(hosts, tmp
         tsv_equal(got.stdout, mout, 3)
         tsv_equal(got.stderr, merr, 0)
         compared += 1
-    assert compared >= 130 and refused <= 8, (compared, refused)
+    assert compared >= 85 and refused <= 6, (compared, refused)
 
 
 @pytest.mark.gpu
@@ -693,7 +693,7 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
             assert (many.returncode, many.stdout, many.stderr) == (one.returncode, one.stdout, one.stderr), (cmd, devs, env, many.stderr[-300:])
         return one
 
-    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::6]
+    cases = helpers.load_golden("ref_kat.json")["cases"] + helpers.load_golden("ref_random.json")["cases"][::9]
     for c in cases:
         f = tmp_path / "in.txt"
         f.write_text(c["input"])

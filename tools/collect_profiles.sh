@@ -26,7 +26,7 @@ done
 python tools/trim_rocprof.py pmc "$(dirname "$(find "$OUT/prof_pmc" -name '*counter_collection.csv' | head -1)")" > "$OUT/pmc_counters.csv" 2>/dev/null || python tools/trim_rocprof.py pmc "$OUT/prof_pmc" > "$OUT/pmc_counters.csv"
 python tools/trim_rocprof.py headline "$OUT/pmc_counters.csv" "$R" "bench.py --steps 3 --warmup 1 --no-cpu --headline-only --prewarm-seconds 0" > "$OUT/pmc_headline.json"; echo "pmc headline rc=$?"
 for n in 1e8 1e9; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k$n" -o k -- python3 tools/pmc_kernels.py $n > "$OUT/kernels_$n.log" 2>&1; echo "kernels $n rc=$?"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k$n" -o k -- python3 tools/pmc_kernels.py $n 10 > "$OUT/kernels_$n.log" 2>&1; echo "kernels $n rc=$?"
   python tools/trim_rocprof.py stats "$(find "$OUT/prof_k$n" -name '*kernel_stats.csv' | head -1)" > "$OUT/kernels_${n}_kernel_stats.csv"
   python tools/trim_rocprof.py timeline "$(find "$OUT/prof_k$n" -name '*kernel_trace.csv' | head -1)" > "$OUT/kernels_${n}_timeline.md"
   # EVERY build kernel's counters (round 5): HBM traffic against the algorithmic bytes, and where the wave cycles go.  Separate
