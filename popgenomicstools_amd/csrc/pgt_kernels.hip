@@ -164,12 +164,17 @@ struct NodeStage {
 // bank selection those bits feed is hit by all of them at once.  Each wave therefore walks its tile from a leaf of its own
 // — a hash of the wave index, in steps of the batch size — and wraps around; a leaf's sum does not depend on when it is read
 // and lane j still keeps leaf j's, so every node is bit for bit what it was.  Interleaved A/B of the two builds in one
-// process (tools/lib_ab.py; profiles/r05/lib_ab_rot*.md; % of the HBM peak, fst build): 10^8 sites 81.3 -> 84.9, 79.5 -> 82.9;
-// 10^9 sites 83.2 -> 85.7, 80.3 -> 81.4.  A plain (4 x wave) & 63 gives the same at 10^8 sites and a point less at 10^9, a
-// start that changes from tile to tile (hash of the tile index) or differs between the two columns of a tile gains less;
-// starts at any leaf (steps of 1 or 2 leaves, the batch wrapping inside) lose a point at 10^8 sites and gain half a point at
-// 10^9; other hashes tie.  The dxy, fused and extreme-score builds walk their tiles the same way: dxy 77.5 -> 82.2 % at 10^8
-// sites, 83.6 -> 85.4 at 10^9; fused 79.2 -> 82.1, 82.6 -> 83.7; extreme score unchanged (lib_ab_rotation_all_*.md).
+// process (tools/lib_ab.py; % of the HBM peak; profiles/r05/ab_series.md, lib_ab_rotation_all_*.md): fst build 79.5 -> 82.9 and
+// 78.8 -> 82.0 at 10^8 sites, 80.3 -> 81.4 and 81.1 -> 82.3 at 10^9 (two more runs, whose files a later run overwrote, read
+// 81.3 -> 84.9 and 83.2 -> 85.7); dxy 77.5 -> 82.2 at 10^8, 83.6 -> 85.4 at 10^9; fused 79.2 -> 82.1, 82.6 -> 83.7; the AF front end
+// +3 ... +5 points at 10^8 (pgt_af_kernels.hip); the extreme-score build unchanged by itself, but its geometry could then be
+// chosen (ext_build_launch).  A plain (4 x wave) & 63 gives the same at 10^8 sites and a point less at 10^9; a start that
+// changes from tile to tile (hash of the tile index) or differs between the two columns of a tile gains less; starts at any
+// leaf (steps of 1 or 2 leaves, the batch wrapping inside) lose a point at 10^8 sites and gain half a point at 10^9; other
+// hashes tie; delaying the waves' starts against each other (s_sleep, 0.3 ... 3 us), odd waves reading `b` before `a`, and the
+// fused build's genotype bursts at a batch of the wave's own gain nothing.  With the rotation in place the launch geometry was
+// measured again (build_ab_fst_geometry_with_rotation*.md): 8 waves per CU x 4 loads stays ahead of 8 / 16 loads (-3 ... -8 %)
+// and of 12 / 16 / 24 / 32 waves per CU with 2 or 4 loads (-1 ... -8 %) at every size.
 template <int U>
 __device__ __forceinline__ int tile_rotation(uint64_t wave) {
     return (int)(((wave * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - U));  // a multiple of U below 64 (U a power of two)
@@ -332,8 +337,9 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
 // scalar registers): bit L of mask c = site 4L + c of the pair.  The lane that owns sites 2l + q (q = 0, 1) of leaf tile h
 // (0, 1) of the pair — pair site 128h + 2l + q, i.e. count lane 32h + (l >> 1), component 2(l & 1) + q — picks its two bits
 // from the masks.  Integer-exact, the f64 arithmetic is untouched: rows bit for bit those of the 8-byte form.
-// MEASURED (interleaved A/B of the two builds in one process, profiles/r05/lib_ab_v1_*.md): a TIE — dxy 80.9 -> 79.8 and
-// 80.1 -> 79.9 % at 10^8 sites, 81.3 -> 82.6 and 80.9 -> 81.0 at 10^9; fused 80.3 -> 80.8 at 10^8.  The guide's 0.54-0.70x for
+// MEASURED (interleaved A/B of the two builds in one process, profiles/r05/lib_ab_v1_1e8.md, ab_series.md `v1_pairs`): a TIE —
+// dxy 80.9 -> 79.8 and 80.1 -> 79.9 % at 10^8 sites, 80.9 -> 81.0 at 10^9 (81.3 -> 82.6 in a run whose file was overwritten);
+// fused 80.3 -> 80.8 at 10^8.  The guide's 0.54-0.70x for
 // 8-byte nt accesses does not bind here: the kernel waits on HBM, not on the load unit.  Kept because every byte of every
 // build kernel is now read by a 16-byte load, the one width rocprofv3's FETCH_SIZE is calibrated for (profiles/r05).
 struct PairPred { unsigned long long m0, m1, m2, m3; };  // four scalars (an array of them lands in scratch)
@@ -370,7 +376,7 @@ __device__ __forceinline__ NodeDxy dxy_leaf_node(const double2 &x1, const double
 // A/B, two boxes (profiles/r03/dxy_ab_*.txt; % of the HBM peak on 24 B/site, the round-2 form -> this one): 10^9 sites
 // 80.0 -> 81.4, 81.7 -> 83.7; 1.25e8 sites 74.5 -> 78.5, 77.1 -> 80.1; 10^8 sites 74.9 -> 79.4, 72.5 -> 75.6.  Waiting after
 // every column (n1 and n2 apart) loses 3-5 points, batches of 8 leaf tiles are no better, batches of 2 are latency-bound.
-// Round 5, five more schedules of the same loads, all bit-identical, none ahead at both sizes (profiles/r05/README.md,
+// Round 5, five more schedules of the same loads, all bit-identical, none ahead at both sizes (profiles/r05/ab_series.md v2-v6,
 // dxy_schedule_variants_rejected.patch): the count columns as 4-load bursts per 8 leaf tiles (ballots kept in scalar
 // registers; -0.9 / -2.8 points at 10^8 / 10^9 sites, with n1 awaited before n2 +1.8 / -2.4); the next batch's p1 burst requested
 // before this batch is computed (+0.5 / -1.6); super-batches of 8 or 16 leaf tiles in which EVERY stream is visited for two or

@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import popgenomicstools_amd as pgt  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
