@@ -178,7 +178,7 @@ def main():
         if kind in ("ihs", "xpehh"):  # no passes mode: an input REALLY beyond the per-GPU limit is refused, nothing printed; one under it runs as ever
             with open(f, "rb") as fh:
                 data = fh.read()
-            n_lines = data.count(b"\n") + (1 if data and not data.endswith(b"\n") else 0)
+            n_lines = data.count(b"\n") + (1 if data and not data.endswith(b"\n") else 0) - (1 if kind == "xpehh" else 0)  # (xpehh: the header line is not a SNP)
             for limit, gpus in ((max(n_lines - 1, 1), 1), (n_lines, 1), (n_lines + 5, 1), ((n_lines + 1) // 2, 2), (max((n_lines - 1) // 2, 1), 2)):
                 env = dict(os.environ, PGT_MAX_RESIDENT_SITES=str(limit))
                 if gpus == 2:
