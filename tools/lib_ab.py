@@ -123,7 +123,17 @@ def main():
             r = fn(c)
             torch.cuda.synchronize()
             return [t.clone() for t in r[:-1] if t is not None]
-        same = all(torch.equal(x, y) for x, y in zip(rows(ctx_a), rows(ctx_b)))
+        ra_, rb_ = rows(ctx_a), rows(ctx_b)
+        same = all(torch.equal(x, y) for x, y in zip(ra_, rb_))
+        if not same:  # say WHICH tensor differs and by how much (a 24-byte tensor is the genome-wide dxy line: f64 sum, two u64 counts)
+            for k, (x, y) in enumerate(zip(ra_, rb_)):
+                if not torch.equal(x, y):
+                    if x.numel() == 24:
+                        fa, fb = x.cpu().numpy().view(np.float64)[0], y.cpu().numpy().view(np.float64)[0]
+                        ia, ib = x.cpu().numpy().view(np.uint64)[1:], y.cpu().numpy().view(np.uint64)[1:]
+                        print(f"  {name}: returned tensor {k} (the genome-wide line) differs: sum {fa!r} vs {fb!r} (relative {abs(fa - fb) / abs(fa):.2e}), counts {ia.tolist()} vs {ib.tolist()}")
+                    else:
+                        print(f"  {name}: returned tensor {k} ({x.numel()} bytes) differs in {int((x != y).sum())} bytes")
         ra, rb, diff, sdiff = [], [], [], []
         for _ in range(rounds):
             a1, b1, b2, a2 = burst(ctx_a, fn), burst(ctx_b, fn), burst(ctx_b, fn), burst(ctx_a, fn)
