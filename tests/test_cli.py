@@ -683,7 +683,7 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
     prints.  stdout, stderr and the exit code must be those of the single-device run, byte for byte: on the
     reference-made goldens (host parser and device parser: with the latter the TEXT is cut at line starts, one piece per
     context, and a context gathers its shard's columns from the pieces), on inputs with a blank-line stop or a bad line in
-    a later piece, and on a 4 * 10^6-line table for fstWindow (steps 10000 and 100: per-window and group query) and hetWindow."""
+    a later piece, and on a 3 * 10^6-line table for fstWindow (steps 10000 and 100: per-window and group query) and hetWindow."""
     import synth
 
     def runs(cmd, **env):
@@ -721,9 +721,9 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
             for W, S in (((340, 136),) if at % 3 else ((340, 136), (3, 2))):
                 r = runs([hosts["hetWindow"], str(g), str(W), str(S)], PGT_GPU_INGEST="1")
                 assert r.returncode == 0
-    # 4 * 10^6 lines (10^7 until round 4: the driver gives the whole GPU suite 900 s)
+    # 3 * 10^6 lines (10^7 until round 4, 4 * 10^6 until round 5: the driver gives the whole GPU suite 900 s)
     rng = np.random.default_rng(31)
-    n = 4_000_000
+    n = 3_000_000
     chr_ids, pos = synth.chromosomes(rng, n, 7, equal=False)
     a, b = synth.fst_columns(rng, n)
     big = tmp_path / "big.fst.txt"
@@ -737,7 +737,7 @@ def test_cli_on_several_gpus_prints_the_single_gpu_tsv(hosts, tmp_path, oracle):
     bigh = tmp_path / "big.het.txt"
     oracle.write_het_text(str(bigh), chr_ids, pos, g)
     r = runs([hosts["hetWindow"], str(bigh), "50000", "10000"], PGT_GPU_INGEST="1")
-    assert r.returncode == 0 and len(r.stdout.splitlines()) > 360
+    assert r.returncode == 0 and len(r.stdout.splitlines()) > n // 10_000 - 7 * 6
 
 
 @pytest.mark.gpu
@@ -1065,8 +1065,7 @@ def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
             text, W, S = mg.random_case(rng, tool, max_chr=6, max_sites=60, max_w=25)
             f = tmp_path / "in.txt"
             f.write_text(text)
-            ref = run([oracle_bind.ref_binary(tool), str(f), str(W), str(S)])
-            mine = run([hosts[tool], str(f), str(W), str(S)])
+            ref, mine = run_all([([oracle_bind.ref_binary(tool), str(f), str(W), str(S)], None), ([hosts[tool], str(f), str(W), str(S)], None)])
             assert mine.returncode == 0 and ref.returncode == 0, (tool, W, S, mine.stderr)
             if tool == "fstWindow":
                 tsv_equal(mine.stdout, ref.stdout, 4)
@@ -1083,8 +1082,7 @@ def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
                 p.write_text(text)
                 paths[name] = str(p)
             argv = [paths[a[1:]] if a.startswith("@") else a for a in args]
-            ref = run([oracle_bind.ref_binary(tool)] + argv)
-            mine = run([hosts_ext[tool]] + argv)
+            ref, mine = run_all([([oracle_bind.ref_binary(tool)] + argv, None), ([hosts_ext[tool]] + argv, None)])
             assert mine.returncode == 0 and ref.returncode == 0, (tool, args, mine.stderr)
             assert mine.stdout == ref.stdout, (tool, args)
             exact += 1
@@ -1102,14 +1100,14 @@ def test_cli_live_against_the_reference_binaries(hosts, hosts_ext, tmp_path):
         g_ = synth.het_column(nrng, n)
         f = tmp_path / "big.txt"
         f.write_text("".join(f"chr{c}\t{p}\t{x:.6f}\t{y:.6f}\n" for c, p, x, y in zip(chr_ids, pos, a_, b_)))
-        ref = run([oracle_bind.ref_binary("fstWindow"), str(f), str(W), str(S)])
-        mine = run([hosts["fstWindow"], str(f), str(W), str(S)])
+        fh_ = tmp_path / "big.het.txt"
+        fh_.write_text("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids, pos, g_)))
+        ref, mine, refh, mineh = run_all([([oracle_bind.ref_binary("fstWindow"), str(f), str(W), str(S)], None), ([hosts["fstWindow"], str(f), str(W), str(S)], None),
+                                          ([oracle_bind.ref_binary("hetWindow"), str(fh_), str(W), str(S)], None), ([hosts["hetWindow"], str(fh_), str(W), str(S)], None)],
+                                         workers=4)  # two of the four are the CPU reference
         assert mine.returncode == 0 and ref.returncode == 0 and len(ref.stdout.splitlines()) > 10, (W, S, mine.stderr)
         tsv_equal(mine.stdout, ref.stdout, 4)
-        f.write_text("".join(f"chr{c}\t{p}\t{v}\n" for c, p, v in zip(chr_ids, pos, g_)))
-        ref = run([oracle_bind.ref_binary("hetWindow"), str(f), str(W), str(S)])
-        mine = run([hosts["hetWindow"], str(f), str(W), str(S)])
-        assert mine.returncode == 0 and mine.stdout == ref.stdout, ("hetWindow", W, S)
+        assert mineh.returncode == 0 and mineh.stdout == refh.stdout, ("hetWindow", W, S)
 
 
 @pytest.mark.gpu
