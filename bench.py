@@ -676,7 +676,10 @@ def main():
         def fence():
             ex.flush()
             if world > 1:
-                dist.barrier(group=group)
+                if coll_dev.type == "cuda":  # RCCL: name this rank's device (the group was created without a bound one)
+                    dist.barrier(group=group, device_ids=[dev_index])
+                else:
+                    dist.barrier(group=group)
             torch.cuda.synchronize()
 
         # bring the GPU to its steady state first: after the set-up phase (host-side table building, allocation) the first legs of a

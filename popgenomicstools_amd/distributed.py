@@ -177,6 +177,14 @@ class RowExchange:
             self.k = 0
             self.last = 0
 
+    def _barrier(self):
+        """Barrier of the exchange's group.  On RCCL (collective tensors on the GPU) the rank's own device is NAMED: a group
+        created without a bound device (lazily, as bench.py does) would otherwise have torch guess it from the rank."""
+        if self.coll_device.type == "cuda":
+            self.dist.barrier(group=self.group, device_ids=[self.coll_device.index if self.coll_device.index is not None else self.torch.cuda.current_device()])
+        else:
+            self.dist.barrier(group=self.group)
+
     # ---- peer ------------------------------------------------------------------------------
     def _setup_peer(self) -> bool:
         dist, torch = self.dist, self.torch
@@ -224,7 +232,7 @@ class RowExchange:
                 torch.cuda.synchronize(self.device)
         except PgtError as e:
             self.peer_error, ok = "self-test store: " + str(e), 0
-        dist.barrier(group=self.group)  # every rank's stores have completed on its side
+        self._barrier()  # every rank's stores have completed on its side
         if self.rank == self.dst and ok:
             try:  # a failing read-back must not keep this rank out of the all_reduce below (every other rank waits there)
                 raw = self.ctx.rowbuf_read(self.buf, self.total)
@@ -284,7 +292,7 @@ class RowExchange:
         torch, dist = self.torch, self.dist
         self.flush()
         if self.world > 1:
-            dist.barrier(group=self.group)  # peer: every rank's row stores have landed in dst's buffer
+            self._barrier()  # peer: every rank's row stores have landed in dst's buffer
         if self.rank != self.dst:
             return None
         if self.mode == "peer":
@@ -302,7 +310,7 @@ class RowExchange:
     def close(self):
         if self.world > 1:
             self.flush()
-            self.dist.barrier(group=self.group)  # nobody unmaps / frees while a peer may still write
+            self._barrier()  # nobody unmaps / frees while a peer may still write
         self._close_peer()
 
 

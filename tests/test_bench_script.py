@@ -180,6 +180,7 @@ with ph('init'):
 t = torch.full((4,), 3.0, device=coll_dev)
 dist.all_reduce(t, group=group)
 w = dist.barrier(group=group)
+dist.barrier(group=group, device_ids=[0])  # the form bench.py and RowExchange use on RCCL: the rank's device is named
 out = [torch.zeros(8, dtype=torch.uint8, device=coll_dev)]
 dist.gather(torch.arange(8, dtype=torch.uint8, device=coll_dev), out, dst=0, group=group)
 print(json.dumps({'desc': desc, 'dev': str(coll_dev), 'sum': float(t.sum().item()), 'gathered': out[0].cpu().tolist()}), flush=True)
