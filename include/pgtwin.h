@@ -134,7 +134,9 @@ int pgt_fst_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *a, const
 int pgt_het_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n,
                        const pgt_win *win, uint64_t n_win, pgt_het_row *out, size_t out_bytes,
                        void *tree, size_t tree_bytes, void *stream);
-/* tot: device pointer to one pgt_dxy_total, or NULL. */
+/* tot: device pointer to one pgt_dxy_total (the genome-wide line, dxyWindow.cpp:382-385,429-433), or NULL.  Its counts are
+ * exact; its sum is added from one partial sum per build wave, in wave order — a function of n alone (the build grid is static),
+ * within 1e-15 relative of any other order of the same additions. */
 int pgt_dxy_reduce_dev(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2,
                        const int32_t *n1, const int32_t *n2, uint64_t n, int minind,
                        const pgt_win *win, uint64_t n_win, pgt_dxy_row *out, size_t out_bytes,
