@@ -244,7 +244,7 @@ def fmt_g6(x):
     return "%g" % x
 
 
-def check_rows_against_tsv(tsv_path, table, win, run_len, n_sample, against):
+def check_rows_against_tsv(tsv_path, table, win, n_sample, against):
     """The LIVE parity check of the headline run (fstWindow.cpp:69-107,150-152): the reference's TSV for the first n_sample
     sites against the rows the GPU produced for the whole genome in the timed run.  Comparable are the windows that end
     inside the sample (the streaming machine emits them before it can know what follows); what the reference prints after
@@ -346,7 +346,7 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
         del text
     rows_check = None
     if table is not None:
-        rows_check = check_rows_against_tsv(tsv, table, win, genome.run_len, n_sample,
+        rows_check = check_rows_against_tsv(tsv, table, win, n_sample,
                                             "reference fstWindow (oracle/_ref/fstWindow, the unmodified reference source compiled)" if ref
                                             else "oracle port (oracle/liboracle.so; the reference binary did not travel)")
     os.unlink(path)

@@ -126,15 +126,15 @@ def test_rows_check_against_the_reference_tsv(tmp_path):
                 subprocess.run([binary, text, str(W), str(S)], stdout=fh, check=True)
         else:
             assert orc.fst_text(text, W, S, tsv) == 0
-        res = bench.check_rows_against_tsv(tsv, table, win, run_len, n_sample, "test")
+        res = bench.check_rows_against_tsv(tsv, table, win, n_sample, "test")
         k = int(np.count_nonzero(win["hi"] <= n_sample))
         assert res["equal"] is True and res["windows"] == k and k > 10 and res["reference_rows"] >= k, res
         for field, delta in (("n", 1), ("end", 1), ("fst", 1e-5)):
             bad = table.copy()
             bad[field][k // 2] += type(bad[field][0])(delta) if field != "fst" else abs(bad["fst"][k // 2]) * delta + 1e-7
-            res = bench.check_rows_against_tsv(tsv, bad, win, run_len, n_sample, "test")
+            res = bench.check_rows_against_tsv(tsv, bad, win, n_sample, "test")
             assert res["equal"] is False and f"row {k // 2}:" in res["mismatch"], (field, res)
         # within 1e-9 relative: still the same printed digits (or a rounding boundary, which is accepted)
         near = table.copy()
         near["fst"] *= 1 + 5e-10
-        assert bench.check_rows_against_tsv(tsv, near, win, run_len, n_sample, "test")["equal"] is True
+        assert bench.check_rows_against_tsv(tsv, near, win, n_sample, "test")["equal"] is True
