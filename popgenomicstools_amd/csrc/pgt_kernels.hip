@@ -109,6 +109,10 @@ struct TreeView {
 // is (i) at least two consecutive batches from the same stream — phases of 16 leaves do as well as 64, phases of one
 // 8-load batch are back at the old rate — and (ii) a SHORT queue: 4 loads in flight beat 8 beat 16 (83.8 / 82.0 / 80.4 at
 // 10^9 sites on one box), 2 and 1 are latency-bound (65 / 40 %); more waves per CU with a shallower stage lose (77 %).
+// IN BURSTS (round 5).  What the "short queue" really is: the four kibibytes of a batch requested back to back — one 4-KiB-aligned
+// contiguous burst per wave — and then nothing until they are consumed.  Refilling every load slot the moment its value is used
+// (four 1-KiB loads in flight at ALL times, a steady trickle instead of bursts) costs 20 points at every size; bursts that do
+// not start on a 4-KiB boundary (a rotation in steps of one or two leaves) cost one (profiles/r05/ab_series.md rolling4, fine1).
 // THE TILE SCHEDULE STAYS STATIC (round 4).  Handing the tiles out by an atomic ticket counter after a static first round
 // (self-resetting counter, one per pair and stream; rows bit-identical) was measured on the fst, dxy, fused and extreme-score
 // builds: -12 ... -23 % at 1e8-1.25e8 sites, -1 ... -3 % at 1e9, with the ticket drawn at the tile's end or half a tile ahead:
