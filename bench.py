@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the 10^8-site configs 2/3/5 (so that a rocprofv3 --stats average covers one size only)")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the single-GPU recomputation on rank 0")
+    ap.add_argument("--no-exchange-overhead", action="store_true",
+                    help="N = 1: skip the leg that prices the multi-GPU row exchange on an RCCL group of one rank (extra.exchange_overhead)")
+    ap.add_argument("--exchange-steps", type=int, default=200, help="steps per figure of the exchange_overhead leg")
     ap.add_argument("--workload", choices=["fst", "pairs"], default="fst",
                     help="fst = the headline 2-population scan (default); pairs = BASELINE configs[4]: all --pairs population pairs "
                          "batched over one window table (use --sites 1e8 --chroms 20), sharded by site range like the headline")
@@ -114,7 +117,7 @@ def self_launch(args) -> int:
 # ---- phases, deadlines, stderr log (stdlib only: usable before torch is imported) -----------------------------
 # seconds; a deadline covers ONE entry of a phase.  PGT_BENCH_DEADLINE_SCALE scales them (tests use 0.1 … 0.3).
 PHASE_DEADLINES_S = {"init": 120, "columns": 90, "gather timed": 60, "peer timed": 60, "local timed": 120, "verify": 120,
-                     "roofline": 30, "extra configs": 600, "sustained": 120, "cpu baseline": 600}
+                     "roofline": 30, "extra configs": 600, "sustained": 120, "cpu baseline": 600, "exchange overhead": 120}
 T_START = time.perf_counter()
 
 
@@ -233,6 +236,7 @@ from popgenomicstools_amd._lib import (DXY_ROW_DTYPE, FST_ROW_DTYPE, HET_ROW_DTY
 from popgenomicstools_amd.distributed import RowExchange  # noqa: E402
 from popgenomicstools_amd.window_scan import windows_to_device  # noqa: E402
 from synth_genome import SynthGenome  # noqa: E402
+from gpu_telemetry import Telemetry, pci_bus_id_of  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy ceiling)
 BYTES_PER_SITE = 16.0  # algorithmic: a,b f64 read once by the tree-build kernel
@@ -244,13 +248,23 @@ def fmt_g6(x):
     return "%g" % x
 
 
-def check_rows_against_tsv(tsv_path, table, win, n_sample, against):
-    """The LIVE parity check of the headline run (fstWindow.cpp:69-107,150-152): the reference's TSV for the first n_sample
-    sites against the rows the GPU produced for the whole genome in the timed run.  Comparable are the windows that end
-    inside the sample (the streaming machine emits them before it can know what follows); what the reference prints after
-    them belongs to the sample's truncated last chromosome.  Coordinates, midpoint, count and label exact; FST as printed
-    (`%g`), or — on a rounding boundary of the six printed digits — printed from a value within 1e-9 relative."""
-    rows = np.frombuffer(table.tobytes(), dtype=FST_ROW_DTYPE)[:win.size]  # pair 0 = the first table
+def checker_tools():
+    """oracle/ (test infrastructure): the text writers, the compiled reference binaries under oracle/_ref and the CPU port.
+    bench.py uses them in exactly two places, both outside every timed region: cpu_baseline (the reported CPU number + the live
+    parity check of the headline rows) and het_rows_check (the live parity check of configs[2]).  Never on the measured path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    return oracle_bind
+
+
+def check_rows_against_tsv(tsv_path, table, win, n_sample, against, row_dtype=None, value="fst", count="n"):
+    """The LIVE parity check of a timed run (fstWindow.cpp:69-107,150-152; hetWindow.cpp:66-105,148-150): the reference's TSV
+    for the first n_sample sites against the rows the GPU produced for the whole genome in the timed run.  Comparable are
+    the windows that end inside the sample (the streaming machine emits them before it can know what follows); what the
+    reference prints after them belongs to the sample's truncated last chromosome.  Coordinates, midpoint, count and label
+    exact; the statistic as printed (`%g`), or — on a rounding boundary of the six printed digits — printed from a value
+    within 1e-9 relative.  row_dtype / value / count: FST rows (`fst`, `n`) by default; het rows are (`h`, `nonmissing`)."""
+    rows = np.frombuffer(table.tobytes(), dtype=row_dtype or FST_ROW_DTYPE)[:win.size]  # pair 0 = the first table
     k = int(np.count_nonzero(win["hi"] <= n_sample))
     assert np.all(win["hi"][:k] <= n_sample), "windows ending inside the sample are a prefix of the table"
     with open(tsv_path) as fh:
@@ -262,9 +276,9 @@ def check_rows_against_tsv(tsv_path, table, win, n_sample, against):
     rounding_boundary = 0
     for i in range(k):
         r = rows[i]
-        want = ["chr%d" % (int(win["label_run"][i]) + 1), str(int(r["start"])), str(int(r["end"])), str(int(r["mid"])), None, str(int(r["n"]))]
+        want = ["chr%d" % (int(win["label_run"][i]) + 1), str(int(r["start"])), str(int(r["end"])), str(int(r["mid"])), None, str(int(r[count]))]
         got = ref_lines[i].split("\t")
-        f = float(r["fst"])
+        f = float(r[value])
         ok = len(got) == 6 and all(w is None or w == g for w, g in zip(want, got))
         if ok and got[4] != fmt_g6(f):
             if got[4] in (fmt_g6(f * (1 + 1e-9)), fmt_g6(f * (1 - 1e-9))) or abs(float(got[4]) - f) <= 1e-9 * abs(f) + 1e-12:
@@ -276,9 +290,41 @@ def check_rows_against_tsv(tsv_path, table, win, n_sample, against):
             res["mismatch"] = f"row {i}: reference {ref_lines[i]!r}, GPU {chr(9).join(want)!r}"
             return res
     res["equal"] = True
-    res["fst_on_a_rounding_boundary"] = rounding_boundary
+    res[value + "_on_a_rounding_boundary"] = rounding_boundary
     res["tsv_sha256"] = hashlib.sha256("\n".join(ref_lines[:k]).encode()).hexdigest()
     return res
+
+
+def het_rows_check(g8, pos, g1, het_table, win_h, W, S, n_sample=20_000_000):
+    """configs[2]'s live reference check (VERDICT round 5, item 5): the UNMODIFIED reference hetWindow (oracle/_ref/hetWindow;
+    hetWindow.cpp:66-105,148-150) on the first n_sample sites of the fused run's g1 column as text (~3 s, outside every timed
+    region) against the het rows the fused dxy + het x2 kernel produced for those windows: coordinates, midpoint and the
+    non-missing count exact, h as printed.  There is no dxy leg: no reference dxyWindow binary exists in this image."""
+    oracle_bind = checker_tools()
+    ref = oracle_bind.ref_binary("hetWindow")
+    orc = oracle_bind.load()
+    tmpdir = tempfile.mkdtemp(prefix="pgt_bench_het_")
+    path, tsv = os.path.join(tmpdir, "sample.het.txt"), os.path.join(tmpdir, "sample.het.tsv")
+    try:
+        orc.write_het_text(path, g8.chr_ids_np(0, n_sample), pos[:n_sample].cpu().numpy().view(np.uint32), g1[:n_sample].cpu().numpy())
+        t0 = time.perf_counter()
+        if ref:
+            with open(tsv, "w") as out_fh:
+                subprocess.run([ref, path, str(W), str(S)], stdout=out_fh, check=True, timeout=300)
+        else:
+            assert orc.het_text(path, W, S, tsv) == 0
+        dt = time.perf_counter() - t0
+        res = check_rows_against_tsv(tsv, het_table, win_h, n_sample,
+                                     "reference hetWindow (oracle/_ref/hetWindow, the unmodified reference source compiled)" if ref
+                                     else "oracle port (oracle/liboracle.so; the reference binary did not travel)",
+                                     row_dtype=HET_ROW_DTYPE, value="h", count="nonmissing")
+        res["sample"] = f"first {n_sample} sites of g1 as text, {dt:.2f} s of the CPU tool"
+        return res
+    finally:
+        for f_ in (path, tsv):
+            if os.path.exists(f_):
+                os.unlink(f_)
+        os.rmdir(tmpdir)
 
 
 def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside=None, table=None, win=None):
@@ -289,8 +335,7 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
     (a few thousand rows) and is compared with the rows of the timed GPU run: -> (cpu_baseline, rows_check).
     beside: callable(done) run on the calling thread WHILE the CPU run goes on a worker thread (its clock is taken there):
     the sustained leg, which keeps the GPU busy for those ~12 s (one of this box's 256 cores launches kernels meanwhile)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_bind
+    oracle_bind = checker_tools()
     orc = oracle_bind.load()
     n_sample = int(min(n_sample, a.numel()))
     hp = pos[:n_sample].cpu().numpy().view(np.uint32)
@@ -426,7 +471,7 @@ def sustained_leg(step, alg_bytes_per_step, sites, seconds=2.5, until=None, max_
             "first_vs_last_chunk": chunk_gbs[-1] / chunk_gbs[0]}
 
 
-def extra_configs(ctx, dev, W, S, tree_pool):
+def extra_configs(ctx, dev, W, S, tree_pool, check_het=True):
     """BASELINE configs 2, 3, 5 (one-GPU forms) at 10^8 sites in 20 chromosomes, same generator."""
     n8 = 100_000_000
     g8 = SynthGenome(SEED, n8, 20)
@@ -447,6 +492,11 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
     out["dxy_het_fused_1e8"] = dict(r, config="BASELINE configs[2]: dxyWindow + hetWindow x2, shared SoA, 1e8 sites, 1 GPU",
                                     kernel="dxy_het_build_kernel")
+    if check_het:
+        fused = ctx.dxy_het_reduce_dev(pos, p1, p2, n1, n2, g1, g2, 5, win, tree=tree_pool)
+        torch.cuda.synchronize()
+        out["dxy_het_fused_1e8"]["rows_check"] = het_rows_check(g8, pos, g1, fused[2].cpu().numpy(), win_h, W, S)
+        del fused
     del p1, p2, n1, n2, g1, g2
     # the same 28 pairs from 8 allele-frequency columns: 64 B/site instead of 448
     fr = [g8.freq_t(k, 0, n8, dev) for k in range(8)]
@@ -507,6 +557,118 @@ def extra_configs(ctx, dev, W, S, tree_pool):
     out["fst_1e7_small_step_query"] = {"config": "fstWindow 1e7 sites, W=50000, S=1 (9.95e6 windows) and S=100 (99501 windows): query kernel only, ms; "
                                                  "the product takes the group query for both (pgt_set_window_step <= 1024, windows >= 16384 sites)",
                                        **q}
+    return out
+
+
+def exchange_overhead(ctx, dev, dev_index, headline_cols, win, tree, W, S, ph, steps=200):
+    """What the multi-GPU row exchange costs PER STEP, measured on this one GPU: the step of the
+    8-GPU run — build + query of ONE shard (1/8 of the window table, pgt_plan_shards) — timed back to back with the rows
+    left where the kernel wrote them ("local") and with the product's RowExchange(mode="gather") running exactly as it
+    does between GPUs: torch.distributed.gather on an RCCL group (here: of one rank — gather to itself), asynchronous,
+    two send buffers and two receive sets, the event waits of begin().  What is NOT in it: the wire (40 B x 12 500 rows
+    = 0.5 MB per step and rank over xGMI) and waiting for slower ranks.  Three workloads: the headline's 8-GPU shard
+    (1.25e8 sites), the whole 10^9-site genome (the N = 1 step with a 4-MB gather), and the 8-GPU shard of BASELINE
+    configs[4] (28 pairs x 1.25e7 sites, 28 x the rows).  local and gather legs alternate (3 rounds), medians reported;
+    the tables of both modes must be equal bit for bit."""
+    from datetime import timedelta
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    t0 = time.perf_counter()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, timeout=timedelta(seconds=60))
+    group = dist.new_group(backend="nccl", timeout=timedelta(minutes=5))  # nccl == RCCL on ROCm
+    probe = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(probe, group=group)
+    torch.cuda.synchronize()
+    assert float(probe.item()) == 1.0
+    bring_up = time.perf_counter() - t0
+    K = max(20, int(steps))
+
+    def one(scan_into, counts, tables, to_self):
+        ex = RowExchange(ctx, counts, FST_ROW_DTYPE.itemsize, dev, dst=0, group=group, mode="gather", tables=tables,
+                         coll_device=dev, gather_to_self=to_self)
+        assert ex.mode == ("gather" if to_self else "local")
+
+        def step():
+            out = ex.begin()
+            scan_into(out)
+            ex.end()
+
+        for _ in range(20):
+            step()
+        ex.flush()
+        t_end = 0.0
+        t1 = time.perf_counter()
+        for _ in range(K):
+            out = ex.begin()
+            scan_into(out)
+            te = time.perf_counter()
+            ex.end()
+            t_end += time.perf_counter() - te
+        t_host = time.perf_counter() - t1  # the host has enqueued everything: how far it runs ahead of the GPU
+        ex.flush()
+        dt = time.perf_counter() - t1
+        table = ex.finish()
+        ex.close()
+        return dt / K * 1e3, t_host / K * 1e3, t_end / K * 1e3, hashlib.sha256(table.tobytes()).hexdigest()
+
+    def workload(name, scan_into, counts, tables, what):
+        loc, gat, host_l, host_g, end_g, sha = [], [], [], [], [], set()
+        for _ in range(3):
+            ms, h, _e, d = one(scan_into, counts, tables, False)
+            loc.append(ms)
+            host_l.append(h)
+            sha.add(d)
+            ms, h, e, d = one(scan_into, counts, tables, True)
+            gat.append(ms)
+            host_g.append(h)
+            end_g.append(e)
+            sha.add(d)
+        l_, g_ = float(np.median(loc)), float(np.median(gat))
+        return {"config": what, "rows_per_step": int(counts[0]), "row_bytes_per_step": int(counts[0]) * FST_ROW_DTYPE.itemsize,
+                "steps_per_figure": K, "local_ms_per_step": l_, "gather_ms_per_step": g_,
+                "overhead_ms_per_step": g_ - l_, "overhead_frac_of_step": (g_ - l_) / l_,
+                "local_ms_all": [round(x, 5) for x in loc], "gather_ms_all": [round(x, 5) for x in gat],
+                "host_enqueue_ms_per_step": {"local": float(np.median(host_l)), "gather": float(np.median(host_g)),
+                                             "of_which_gather_call": float(np.median(end_g))},
+                "tables_equal_bitwise": len(sha) == 1}
+
+    out = {"collective": "torch.distributed.gather on an RCCL (nccl) group of ONE rank, async_op, double-buffered (RowExchange mode 'gather', "
+                         "gather_to_self) vs rows left in place ('local'); alternating legs, medians of 3",
+           "rccl_bring_up_seconds": round(bring_up, 2)}
+    pos, a, b = headline_cols
+    n_total = int(a.numel())
+    # (a) the 8-GPU shard of the headline genome (rank 0's: sites [0, site_hi))
+    sh8 = pgt.plan_shards(win, 8)[0]
+    lo, hi = int(sh8["site_lo"]), int(sh8["site_hi"])
+    assert lo == 0
+    loc_w = np.array(win[int(sh8["win_begin"]): int(sh8["win_end"])], dtype=WIN_DTYPE, copy=True)
+    wd8 = windows_to_device(loc_w, dev)
+    p8, a8, b8 = pos[lo:hi], a[lo:hi], b[lo:hi]
+    out["fst_shard_of_8"] = workload("fst", lambda o: ctx.fst_reduce_dev(p8, a8, b8, wd8, out=o, tree=tree), [loc_w.size], 1,
+                                     f"rank 0's shard of the {n_total:.0e}-site headline genome cut 8 ways: {hi - lo} sites resident, "
+                                     f"{loc_w.size} windows per step")
+    # (b) the whole genome: the N = 1 step with its 4-MB table gathered every step
+    wd1 = windows_to_device(win, dev)
+    out["fst_whole_genome"] = workload("fst", lambda o: ctx.fst_reduce_dev(pos, a, b, wd1, out=o, tree=tree), [win.size], 1,
+                                       f"the whole {n_total:.0e}-site genome, {win.size} windows per step")
+    del wd8, wd1
+    # (c) BASELINE configs[4] cut 8 ways: 28 pairs x 1.25e7 sites, 28 tables of rows per step
+    n8 = min(100_000_000, n_total)  # (a smaller genome only in the tests' small runs)
+    g8 = SynthGenome(SEED, n8, 20)
+    win8 = pgt.build_windows_sites(g8.run_len, W, S)
+    shp = pgt.plan_shards(win8, 8)[0]
+    lo, hi = int(shp["site_lo"]), int(shp["site_hi"])
+    loc_p = np.array(win8[int(shp["win_begin"]): int(shp["win_end"])], dtype=WIN_DTYPE, copy=True)
+    wdp = windows_to_device(loc_p, dev)
+    pp = g8.pos_t(lo, hi, dev)
+    cols = [g8.pair_columns_t(k, lo, hi, dev) for k in range(28)]
+    al, bl = [c[0] for c in cols], [c[1] for c in cols]
+    out["pairs28_shard_of_8"] = workload("pairs", lambda o: ctx.fst_reduce_pairs_dev(pp, al, bl, wdp, out=o, tree=tree), [28 * loc_p.size], 28,
+                                         f"rank 0's shard of BASELINE configs[4] (28 pairs x {n8:.0e} sites) cut 8 ways: {hi - lo} sites resident, "
+                                         f"{loc_p.size} windows x 28 tables per step")
+    del cols, al, bl, pp, wdp
+    dist.destroy_process_group()
     return out
 
 
@@ -614,6 +776,8 @@ def main():
     dev_index = 0 if os.environ.get("PGT_BENCH_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    tel = Telemetry(pci_bus_id_of(dev_index)) if rank == 0 else None  # sysfs / amdsmi only: no HIP call, no process started
+    telemetry = {"reader": tel.describe(), "at_start": tel.snapshot()} if tel else {}
     group, coll_dev, backend_desc = None, dev, "none (single GPU)"
     if world > 1:
         with ph("init"):
@@ -728,7 +892,14 @@ def main():
                                  group=group)
             except PgtError as e:  # peer: the buffer cannot be mapped by every rank (decided collectively)
                 return {"mode": mode, "available": False, "why": str(e)}
-            dt_ = timed_region(ex)
+            if tel and "timed_region" not in telemetry:  # a sampler thread beside the headline's timed region (prewarm included)
+                telemetry["before_timed"] = tel.snapshot()
+                with tel.sampling(period_s=0.05) as smp:
+                    dt_ = timed_region(ex)
+                telemetry["timed_region"] = smp.summary()
+                telemetry["after_timed"] = tel.snapshot(light=True)
+            else:
+                dt_ = timed_region(ex)
             table_ = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
         res = {"mode": ex.mode, "available": True, "dt": dt_, "table": table_, "verified": None}
         if world > 1:
@@ -832,7 +1003,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             # every transport that ran delivered the single-GPU table (or was not verifiable by request)
-            "ok": all(r["verified"] is not False for r in usable) and (ref_check is None or bool(ref_check["equal"])) and not degraded,
+            "ok": (all(r["verified"] is not False for r in usable) and (ref_check is None or bool(ref_check["equal"])) and not degraded
+                   and bool(extra.get("dxy_het_fused_1e8", {}).get("rows_check", {"equal": True})["equal"])),
             "degraded": degraded,
             "config": {"workload": (f"fstWindow 2 pops x {n_total:.0e} sites total" if not pairs_mode else
                                     f"fstWindow all {n_tables} pairs of 8 populations x {n_total:.0e} sites total, one batched call per step,")
@@ -903,13 +1075,15 @@ def main():
     if rank == 0 and world == 1 and not pairs_mode:
         if not args.headline_only:
             with ph("extra configs"):
-                extra = extra_configs(ctx, dev, W, S, tree)
+                extra = extra_configs(ctx, dev, W, S, tree, check_het=not args.no_cpu)
                 ctx.set_max_window(int((win["hi"] - win["lo"]).max()))
                 ctx.set_window_step(S)
         sust_out = torch.empty(max(int(counts[rank]) * FST_ROW_DTYPE.itemsize, 1), dtype=torch.uint8, device=dev)
 
         def sustained(until=None):
-            extra["sustained"] = sustained_leg(lambda: scan(mycols, win_d, sust_out, tree), BYTES_PER_SITE * n, n, until=until)
+            with tel.sampling(period_s=0.1) as smp:
+                extra["sustained"] = sustained_leg(lambda: scan(mycols, win_d, sust_out, tree), BYTES_PER_SITE * n, n, until=until)
+            telemetry["sustained"] = smp.summary()
 
         if args.no_cpu and not args.headline_only:
             with ph("sustained"):
@@ -919,6 +1093,19 @@ def main():
                 cpu, ref_check = cpu_baseline(pos, a, b, genome, W, S, args.cpu_sites, ctx, extra, beside=None if args.headline_only else sustained,
                                               table=runs[0]["table"], win=win)
         del sust_out
+        if not args.headline_only and not args.no_exchange_overhead:
+            # LAST, and degradable: everything else is in hand — should RCCL wedge on this box, the watchdog prints the line
+            # without this leg (exit 0) instead of losing the run
+            ph.secure(lambda why: assemble(runs, build_avg, query_avg, dict(extra, exchange_overhead={"available": False, "why": why},
+                                                                             telemetry=telemetry), cpu, ref_check=ref_check))
+            with ph("exchange overhead", degradable=True):
+                try:
+                    extra["exchange_overhead"] = exchange_overhead(ctx, dev, dev_index, (pos, a, b), win, tree, W, S, ph, steps=args.exchange_steps)
+                except Exception as e:  # noqa: BLE001 — RCCL absent / refused: reported, the headline stands
+                    extra["exchange_overhead"] = {"available": False, "why": f"{type(e).__name__}: {e}"}
+    if tel:
+        telemetry["at_end"] = tel.snapshot()
+        extra = dict(extra, telemetry=telemetry)
 
     if rank == 0:
         print(assemble(runs, build_avg, query_avg, extra, cpu, ref_check=ref_check), flush=True)
@@ -928,6 +1115,11 @@ def main():
     ph.close()
     if ref_check is not None and not ref_check["equal"]:  # N = 1: the timed run's rows differ from the reference's TSV
         print("bench.py: rows of the timed run DIFFER from the reference's TSV on the CPU-baseline sample: " + ref_check.get("mismatch", "?"),
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    het_check = extra.get("dxy_het_fused_1e8", {}).get("rows_check") if isinstance(extra, dict) else None
+    if het_check is not None and not het_check["equal"]:  # configs[2]: the fused kernel's het rows differ from the reference's TSV
+        print("bench.py: het rows of the fused dxy + het run DIFFER from the reference hetWindow's TSV: " + het_check.get("mismatch", "?"),
               file=sys.stderr, flush=True)
         sys.exit(3)
     if world > 1:

@@ -17,7 +17,9 @@
  *     retrievable with pgt_last_error(ctx) (ctx may be NULL for the ctx-less functions);
  *     the reference's tools exit 255 on error (`return -1`, fstWindow.cpp:42,48,55) and the
  *     retained C++ hosts do the same after printing that message;
- *   - the caller owns every buffer; the library retains nothing past return;
+ *   - the caller owns every buffer; the library retains none of the caller's memory past return (a context keeps
+ *     its own scratch between calls: the pinned staging ring and the window / row / tree workspace of the host-buffer
+ *     entry points, 64 MiB + about 1 % of the largest input seen; pgt_close frees them);
  *   - one pgt_ctx per GPU and per thread (one process per GPU); a ctx is not thread-safe;
  *   - there is NO CPU fallback: without a usable gfx950 device pgt_open fails.
  */
@@ -34,7 +36,9 @@ extern "C" {
 /* 5 (round 5): the i32 count columns of the dxy entry points must be 16-byte aligned (8 sufficed); pgt_tree_bytes(PGT_STAT_DXY)
  * includes the build waves' partial sums; pgt_extreme_reduce_cols, PGT_TOK_CHR_PREFIX and 12 tokens per line (added under
  * version 4 in round 4) are part of it.  A binding written for one version never calls a library of another. */
-#define PGT_ABI_VERSION 5
+/* 6 (round 6): pgt_prepare_host_io added; the host-buffer entry points stage their uploads through a per-context pinned
+ * ring and keep a per-context workspace (no argument list changed). */
+#define PGT_ABI_VERSION 6
 
 enum {
     PGT_OK = 0,
@@ -88,6 +92,11 @@ pgt_ctx *pgt_open(int device);
 void pgt_close(pgt_ctx *ctx);
 const char *pgt_last_error(const pgt_ctx *ctx);
 int pgt_abi_version(void);
+/* Optional: allocate the pinned staging ring of the host-buffer entry points (pgt_*_reduce with host columns) now
+ * (~15 ms of hipHostMalloc) instead of inside the first such call — the retained hosts call it on the thread that opens
+ * the device, beside the text parse.  Replaces nothing in the reference (its calcWindow reads the caller's buffer in place,
+ * fstWindow.cpp:76-83); it exists because the columns have to cross PCIe here. */
+int pgt_prepare_host_io(pgt_ctx *ctx);
 
 /* ---- window tables (host, O(#windows + #runs), no device needed) ------------------------ */
 /* Site-count windows of fstWindow / hetWindow / dxyWindow -fixedsite 1: the emission rules of

@@ -13,7 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpgtwin.so")
 
-PGT_ABI_VERSION = 5
+PGT_ABI_VERSION = 6
 PGT_OK, PGT_EARG, PGT_ECAP, PGT_EDEVICE, PGT_EDOMAIN, PGT_ENOMEM = range(6)
 PGT_WIN_COORDS = 1
 PGT_STAT_FST, PGT_STAT_HET, PGT_STAT_DXY, PGT_STAT_EXT = 0, 1, 2, 3
@@ -39,7 +39,7 @@ assert DXY_ROW_DTYPE.itemsize == 24 and DXY_TOTAL_DTYPE.itemsize == 24 and SHARD
 
 # every symbol include/pgtwin.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "pgt_open", "pgt_close", "pgt_last_error", "pgt_abi_version",
+    "pgt_open", "pgt_close", "pgt_last_error", "pgt_abi_version", "pgt_prepare_host_io",
     "pgt_build_windows_sites", "pgt_build_windows_bp", "pgt_build_windows_extreme",
     "pgt_extreme_reduce", "pgt_extreme_reduce_dev",
     "pgt_fst_reduce", "pgt_het_reduce", "pgt_dxy_reduce",
@@ -81,6 +81,20 @@ def load() -> C.CDLL:
         pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
+    # fail at load time, not at first use, and say what is wrong — BEFORE any symbol is touched (a library too old to export
+    # pgt_abi_version, or some other .so under that name, must not surface as a bare AttributeError): the version first
+    # (argument lists changed between ABI versions: never call across them), then any symbol the binding declares and the
+    # library lacks
+    rebuild = " (rebuild: python -m popgenomicstools_amd.build --force)"
+    if not hasattr(lib, "pgt_abi_version"):
+        raise RuntimeError(f"{LIB_PATH} does not export pgt_abi_version: not a libpgtwin this binding (ABI {PGT_ABI_VERSION}) can use" + rebuild)
+    lib.pgt_abi_version.restype = i32
+    if lib.pgt_abi_version() != PGT_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.pgt_abi_version()}, this binding is written for {PGT_ABI_VERSION}" + rebuild)
+    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} is older than this binding although it reports ABI version {PGT_ABI_VERSION}: it lacks "
+                           + ", ".join(missing) + rebuild)
     lib.pgt_open.restype = vp
     lib.pgt_open.argtypes = [i32]
     lib.pgt_close.restype = None
@@ -157,14 +171,7 @@ def load() -> C.CDLL:
     lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, vp]
-    # fail at load time, not at first use, and say what is wrong: the version first (argument lists changed between ABI
-    # versions: never call across them), then any symbol the binding declares and the library lacks
-    if lib.pgt_abi_version() != PGT_ABI_VERSION:
-        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.pgt_abi_version()}, this binding is written for {PGT_ABI_VERSION}")
-    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
-    if missing:
-        raise RuntimeError(f"{LIB_PATH} is older than this binding although it reports ABI version {PGT_ABI_VERSION}: it lacks "
-                           + ", ".join(missing) + " (rebuild: python -m popgenomicstools_amd.build --force)")
+    lib.pgt_prepare_host_io.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "pgt_device.h"
 #include "pgt_internal.h"
@@ -55,31 +56,50 @@ struct AfCols {
     double nsamp[kAfMaxPops];
 };
 
-// ---- exchange with lane ^ mask, cheapest mechanism per mask ------------------------------------
-constexpr int kRsMask[6] = {1, 2, 8, 4, 16, 32};  // order: the steps with most exchanges use DPP
+// ---- reduce-scatter across the wave ----------------------------------------------------------------
+// Step order: the steps with the MOST exchanges (18 and 9 of the 38 at 8 populations) pair lanes across the wave halves and
+// across 16-lane rows, where gfx950 has an instruction made for exactly this exchange: v_permlane32_swap / v_permlane16_swap
+// swap the upper lanes of one register with the lower lanes of another, so that "keep one half of my values, receive the
+// other half of my partner's" is two swaps (low and high dword) and ONE addition — no select, no LDS crossbar.  Until round
+// 6 these two steps came last (xor 16 by ds_swizzle, xor 32 by ds_bpermute) and the 27 busiest exchanges cost 4 v_cndmask +
+// 2 DPP moves + 1 add each (profiles/r06/af8_issue_stall.md: 29 % of the wave cycles were instruction-issue waits, the
+// kernel ran 2 waves per SIMD at 228 VGPRs).  The remaining steps (5 + 3 + 2 + 1 exchanges) stay on DPP / ds_swizzle.
+constexpr int kRsMask[6] = {32, 16, 1, 2, 8, 4};
 template <int STEP>
 __device__ __forceinline__ double xchg(double v) {
+    static_assert(STEP >= 2, "steps 0 and 1 are swaps (rs_swap)");
     int lo = __double2loint(v), hi = __double2hiint(v);
-    if constexpr (STEP == 0) {         // xor 1: quad_perm [1,0,3,2]
+    if constexpr (STEP == 2) {         // xor 1: quad_perm [1,0,3,2]
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
         hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
-    } else if constexpr (STEP == 1) {  // xor 2: quad_perm [2,3,0,1]
+    } else if constexpr (STEP == 3) {  // xor 2: quad_perm [2,3,0,1]
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);
         hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
-    } else if constexpr (STEP == 2) {  // xor 8: row_ror:8 inside the 16-lane row
+    } else if constexpr (STEP == 4) {  // xor 8: row_ror:8 inside the 16-lane row
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
         hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
-    } else if constexpr (STEP == 3) {  // xor 4: ds_swizzle bit mode (and 0x1f, or 0, xor 4)
+    } else {                           // xor 4: ds_swizzle bit mode (and 0x1f, or 0, xor 4)
         lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F);
         hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);
-    } else if constexpr (STEP == 4) {  // xor 16: ds_swizzle bit mode
-        lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
-        hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-    } else {                           // xor 32: across the two 32-lane halves
-        lo = __shfl_xor(lo, 32, kWave);
-        hi = __shfl_xor(hi, 32, kWave);
     }
     return __hiloint2double(hi, lo);
+}
+
+// lower lanes (mask bit clear) keep `a` and receive the partner's `a`; upper lanes keep `b` and receive the partner's `b`:
+// after the swaps register A holds {own a | partner's b} and B {partner's a | own b}, so A + B is the exchange's result
+// in every lane (an addition is commutative bit for bit: own + received = received + own).
+template <int STEP>
+__device__ __forceinline__ double rs_swap(double a, double b) {
+    const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    if constexpr (STEP == 0) {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+    }
 }
 
 // One reduce-scatter step: C live values -> (C+1)/2.  A lane whose mask bit is set keeps the upper
@@ -88,14 +108,19 @@ template <int C, int STEP>
 __device__ __forceinline__ void rs_steps(double *v, int lane) {
     if constexpr (STEP < 6) {
         constexpr int H = (C + 1) / 2;
-        const bool up = (lane & kRsMask[STEP]) != 0;
+        if constexpr (STEP < 2) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const double lo_v = v[k];
-            const double hi_v = (k + H < C) ? v[k + H] : 0.0;
-            const double keep = up ? hi_v : lo_v;
-            const double send = up ? lo_v : hi_v;
-            v[k] = keep + xchg<STEP>(send);
+            for (int k = 0; k < H; ++k) v[k] = rs_swap<STEP>(v[k], (k + H < C) ? v[k + H] : 0.0);
+        } else {
+            const bool up = (lane & kRsMask[STEP]) != 0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const double lo_v = v[k];
+                const double hi_v = (k + H < C) ? v[k + H] : 0.0;
+                const double keep = up ? hi_v : lo_v;
+                const double send = up ? lo_v : hi_v;
+                v[k] = keep + xchg<STEP>(send);
+            }
         }
         rs_steps<H, STEP + 1>(v, lane);
     }
@@ -116,17 +141,21 @@ __device__ __forceinline__ int rs_my_index(int lane) {
 }
 
 // ---- per-site contributions ----------------------------------------------------------------------
-template <int NP>
+// FIRST: the leaf's first site STARTS the sums — x*y is bit for bit fma(x, y, +0.0) (one rounding either way; a product that
+// rounds to -0.0 would differ, but both factors' signs make these products >= +0.0: d*d, and 2f(1-f) for 0 <= f <= 1; a
+// frequency outside [0, 1] is outside WCFst's domain) — and saves the 36 register clears per leaf.
+template <int NP, bool FIRST = false>
 __device__ __forceinline__ void af_accumulate(double *vals, const double *f) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) vals[i] = fma(2.0 * f[i], 1.0 - f[i], vals[i]);  // alpha_i, betaAFOutlier.R:408-409
+    for (int i = 0; i < NP; ++i)  // alpha_i, betaAFOutlier.R:408-409
+        vals[i] = FIRST ? (2.0 * f[i]) * (1.0 - f[i]) + 0.0 : fma(2.0 * f[i], 1.0 - f[i], vals[i]);
     int p = NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
         for (int j = i + 1; j < NP; ++j) {
             const double d = f[i] - f[j];
-            vals[p] = fma(d, d, vals[p]);  // explicit FMA: one op, one rounding (the TU is built with -ffp-contract=off)
+            vals[p] = FIRST ? d * d : fma(d, d, vals[p]);  // explicit FMA: one op, one rounding (the TU is built with -ffp-contract=off)
             ++p;
         }
 }
@@ -147,9 +176,13 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
     constexpr int V = Shape<NP>::kVals;
 
     const int lane = threadIdx.x & (kWave - 1);
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // the wave's index, SAID to be wave-uniform (readfirstlane): tile base, rotation and every column address are then scalar
+    // registers and a load is `global_load_dwordx4 v, v_lane_offset, s[base]` — with the index derived from threadIdx the
+    // compiler carried 64-bit per-lane addresses for all 8 columns (91 v_lshl_add_u64 per two pieces, 16+ VGPRs)
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int my = rs_my_index<V>(lane);
+    const uint32_t lane_bytes = (uint32_t)lane * 16u;  // the lane's 16 bytes of a 1-KiB piece: the only per-lane part of an address
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
     // Level-1 nodes are staged in LDS and leave once per level-2 tile as ONE contiguous block (node-major
     // tree: 32 nodes x V doubles = 9 KiB at 8 populations).  History with 128-site leaves, 8 populations, % of
@@ -171,22 +204,19 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
         // partial last tile is walked from its start (its guarded loads stop at n).
         const int rot = full ? (int)(((wave0 * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - (BURST > 0 ? BURST : 4))) : 0;
         double l2acc = 0.0;
-        double2 cur[NP];
-        auto load_tile = [&](double2 *dst, int j) {
-            if (full) {
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-                    dst[k] = load16<true>(reinterpret_cast<const double2 *>(cols.f[k] + base) + j * kWave + lane);
-            } else {  // last, partial level-2 tile: guarded loads; f = 0 contributes nothing
-                const uint64_t i0 = base + (uint64_t)j * kLeafF64 + 2 * lane;
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    dst[k].x = i0 < n ? cols.f[k][i0] : 0.0;
-                    dst[k].y = i0 + 1 < n ? cols.f[k][i0 + 1] : 0.0;
-                }
-            }
-        };
         double vals[V];
+        auto load_full = [&](double2 *dst, int j) {  // piece j of a FULL tile: one 16-byte nt load per lane and column
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                dst[k] = load16<true>(reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(cols.f[k] + base + (uint64_t)j * kLeafF64) + lane_bytes));
+        };
+        auto reduce_piece = [&](auto first, const double2 *pc) {  // the lane's two sites of one piece into the leaf's running sums
+            double fx[NP], fy[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { fx[k] = pc[k].x; fy[k] = pc[k].y; }
+            af_accumulate<NP, decltype(first)::value>(vals, fx);  // a leaf's first site starts the sums
+            af_accumulate<NP>(vals, fy);
+        };
         if constexpr (BURST > 0) {
             if (full) {
 #pragma unroll 1
@@ -197,20 +227,17 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
                     for (int k = 0; k < NP; ++k) {
 #pragma unroll
                         for (int u = 0; u < BURST; ++u)
-                            d[k][u] = load16<true>(reinterpret_cast<const double2 *>(cols.f[k] + base) + (j0 + u) * kWave + lane);
+                            d[k][u] = load16<true>(reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(cols.f[k] + base + (uint64_t)(j0 + u) * kLeafF64) + lane_bytes));
                         if (k + 1 < NP) load_fence(d[k][BURST - 1].y);
                     }
 #pragma unroll
                     for (int u = 0; u < BURST; ++u) {
                         const int j = j0 + u;
-                        if ((u & (kAfPieces - 1)) == 0) {
-#pragma unroll
-                            for (int v = 0; v < V; ++v) vals[v] = 0.0;
-                        }
                         double fx[NP], fy[NP];
 #pragma unroll
                         for (int k = 0; k < NP; ++k) { fx[k] = d[k][u].x; fy[k] = d[k][u].y; }
-                        af_accumulate<NP>(vals, fx);
+                        if ((u & (kAfPieces - 1)) == 0) af_accumulate<NP, true>(vals, fx);  // a leaf's first site starts the sums
+                        else af_accumulate<NP>(vals, fx);
                         af_accumulate<NP>(vals, fy);
                         if ((u & (kAfPieces - 1)) == kAfPieces - 1) {
                             rs_steps<V, 0>(vals, lane);
@@ -220,29 +247,41 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
                 }
             }
         }
-        if (BURST == 0 || !full) {
-        load_tile(cur, rot);
-#pragma unroll kAfPieces
-        for (int i = 0; i < kRadix; ++i) {  // 64 pieces of 128 sites; two consecutive pieces make one 256-site leaf
-            const int j = (i + rot) & (kRadix - 1);  // rot is even: i and j have the same parity, a leaf's two pieces stay together
-            double2 nxt[NP];
-            if (i + 1 < kRadix) load_tile(nxt, (j + 1) & (kRadix - 1));  // next piece's loads fly while this one is reduced
-            if ((i & (kAfPieces - 1)) == 0) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) vals[v] = 0.0;
-            }
-            double fx[NP], fy[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { fx[k] = cur[k].x; fy[k] = cur[k].y; }
-            af_accumulate<NP>(vals, fx);
-            af_accumulate<NP>(vals, fy);
-            if ((i & (kAfPieces - 1)) == kAfPieces - 1) {  // the leaf is complete: one reduce-scatter per leaf
-                rs_steps<V, 0>(vals, lane);
+        if (BURST == 0 && full) {
+            // Piece by piece, software-pipelined over TWO register sets that swap roles without a copy (round 6: the `cur = nxt`
+            // of the rolled form cost 16 v_mov_b64 per piece once the partial-tile branch shared its loop): while leaf q's first
+            // piece (set A) is reduced its second (set B) is in flight, while B is reduced the next leaf's first piece is.
+            double2 pa[NP], pb[NP];
+            load_full(pa, rot);
+#pragma unroll 1
+            for (int i = 0; i < kRadix; i += kAfPieces) {
+                const int j = (i + rot) & (kRadix - 1);  // rot is even: a leaf's two pieces stay together
+                load_full(pb, j + 1);
+                reduce_piece(std::true_type{}, pa);
+                if (i + kAfPieces < kRadix) load_full(pa, (j + kAfPieces) & (kRadix - 1));
+                reduce_piece(std::false_type{}, pb);
+                rs_steps<V, 0>(vals, lane);  // the leaf is complete: one reduce-scatter per leaf
                 if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
             }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
         }
+        if (!full) {  // the last, partial level-2 tile (one wave of the grid, once): guarded loads, no prefetch; f = 0 contributes nothing
+#pragma unroll 1
+            for (int q = 0; q < kAfRadix1; ++q) {
+#pragma unroll 1
+                for (int h = 0; h < kAfPieces; ++h) {
+                    const uint64_t i0 = base + (uint64_t)(q * kAfPieces + h) * kLeafF64 + 2 * lane;
+                    double2 pc[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        pc[k].x = i0 < n ? cols.f[k][i0] : 0.0;
+                        pc[k].y = i0 + 1 < n ? cols.f[k][i0 + 1] : 0.0;
+                    }
+                    if (h == 0) reduce_piece(std::true_type{}, pc);
+                    else reduce_piece(std::false_type{}, pc);
+                }
+                rs_steps<V, 0>(vals, lane);
+                if (my >= 0) stage[q * V + my] = vals[0];
+            }
         }
         // the level-2 node = the 32 leaf nodes added in LEAF order, whatever order they were produced in (they were added as
         // produced until round 5: now the walk starts somewhere else in every wave, and the node must not depend on the wave)

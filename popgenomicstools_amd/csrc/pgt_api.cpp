@@ -4,13 +4,40 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgt_internal.h"
+
+// Host I/O of the host-buffer entry points (pgt_fst_reduce & co., what INTEGRATION.md binds), kept per context:
+//  * a PINNED STAGING RING for the column uploads: `workers` host threads copy 8-MiB pieces of the caller's pageable columns
+//    into their own two pinned slots and queue the DMA of each piece themselves (hipMemcpyAsync on one copy stream), so the
+//    host-side memcpy of piece k+1 overlaps the DMA of piece k and nothing of the caller's memory has to be page-locked.
+//    A plain hipMemcpy from pageable memory lets the runtime pin the caller's pages first: 0.45 ms/MiB the first time a
+//    range is seen (tools/probes/upload_probe.cpp on the gpurun box: 182 ms for 400 MiB, 7.5 ms for the same buffer again)
+//    — and a command-line tool sees every range for the first time;
+//  * a CACHED WORKSPACE (window table, rows, tree, genome-wide total): grown when a call needs more, freed by pgt_close —
+//    tools that reduce in passes call these entry points once per pass with the same sizes.
+struct HostIo {
+    static constexpr int kMaxWorkers = 16, kSlots = 2 * kMaxWorkers;
+    static constexpr size_t kChunk = (size_t)8 << 20;  // threshold for taking the ring at all: 4 of these
+    int workers = 4;                   // PGT_UPLOAD_WORKERS (1 … 16)
+    size_t chunk = (size_t)8 << 20;    // PGT_UPLOAD_CHUNK_MIB (1 … 64); two slots of this size per worker
+    bool ring_ready = false;
+    char *pin[kSlots] = {};
+    hipEvent_t slot_done[kSlots] = {};
+    hipStream_t copy_stream = nullptr;
+    enum { kWin = 0, kRows, kTree, kTot, kKinds };
+    void *ws[kKinds] = {};
+    size_t ws_bytes[kKinds] = {};
+};
 
 struct pgt_ctx {
     int device = 0;
@@ -19,6 +46,7 @@ struct pgt_ctx {
     bool have_timing = false;
     pgt::Hints hints;  // pgt_set_max_window / pgt_set_window_step (0 = unknown)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // build start, build end, query end
+    HostIo io;
 };
 
 namespace {
@@ -46,19 +74,146 @@ int room_check(pgt_ctx *ctx, const char *who, uint64_t rows, size_t row_bytes, s
     return PGT_OK;
 }
 
-// RAII device buffer for the host-buffer entry points
+// RAII device buffer for the host-buffer entry points (the columns: as large as the input, not cached)
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(pgt_ctx *ctx, size_t bytes, const char *what) {
         return hip_check(ctx, hipMalloc(&p, bytes ? bytes : 16), what);
     }
-    int upload(pgt_ctx *ctx, const void *src, size_t bytes, const char *what) {
-        if (int rc = alloc(ctx, bytes, what)) return rc;
-        if (!bytes) return PGT_OK;
-        return hip_check(ctx, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), what);
+};
+
+// PGT_TRACE_API=1: one stderr line per phase of a host-buffer entry point (where a call's milliseconds go)
+struct ApiTrace {
+    const char *who;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit ApiTrace(const char *w) : who(w), on(std::getenv("PGT_TRACE_API") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what, size_t bytes = 0) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - t).count();
+        if (bytes) std::fprintf(stderr, "[pgt-api] %s: %-18s %9.3f ms  %8.1f MB  %6.1f GB/s\n", who, what, ms, bytes / 1e6, bytes / ms / 1e6);
+        else std::fprintf(stderr, "[pgt-api] %s: %-18s %9.3f ms\n", who, what, ms);
+        t = now;
     }
 };
+
+// the cached workspace: -> a device pointer good for `bytes` until the next call that asks for more of the same kind
+int workspace(pgt_ctx *ctx, int kind, size_t bytes, void **out) {
+    HostIo &io = ctx->io;
+    if (bytes == 0) bytes = 16;
+    if (io.ws_bytes[kind] < bytes) {
+        if (io.ws[kind]) (void)hipFree(io.ws[kind]);
+        io.ws[kind] = nullptr;
+        io.ws_bytes[kind] = 0;
+        const size_t want = (bytes + (bytes >> 3) + 4095) & ~(size_t)4095;  // 12 % of slack: passes of slightly different sizes
+        if (int rc = hip_check(ctx, hipMalloc(&io.ws[kind], want), "workspace: hipMalloc")) return rc;
+        io.ws_bytes[kind] = want;
+    }
+    *out = io.ws[kind];
+    return PGT_OK;
+}
+
+int ring_prepare(pgt_ctx *ctx) {
+    HostIo &io = ctx->io;
+    if (io.ring_ready) return PGT_OK;
+    if (const char *e = std::getenv("PGT_UPLOAD_WORKERS")) io.workers = std::min(std::max(std::atoi(e), 1), (int)HostIo::kMaxWorkers);
+    if (const char *e = std::getenv("PGT_UPLOAD_CHUNK_MIB")) io.chunk = (size_t)std::min(std::max(std::atoi(e), 1), 64) << 20;
+    if (int rc = hip_check(ctx, hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking), "upload ring: hipStreamCreate")) return rc;
+    for (int s = 0; s < 2 * io.workers; ++s) {
+        if (int rc = hip_check(ctx, hipHostMalloc(reinterpret_cast<void **>(&io.pin[s]), io.chunk, hipHostMallocDefault), "upload ring: hipHostMalloc")) return rc;
+        if (int rc = hip_check(ctx, hipEventCreateWithFlags(&io.slot_done[s], hipEventDisableTiming), "upload ring: hipEventCreate")) return rc;
+    }
+    io.ring_ready = true;
+    return PGT_OK;
+}
+
+void host_io_release(pgt_ctx *ctx) {
+    HostIo &io = ctx->io;
+    for (int s = 0; s < HostIo::kSlots; ++s) {
+        if (io.pin[s]) (void)hipHostFree(io.pin[s]);
+        if (io.slot_done[s]) (void)hipEventDestroy(io.slot_done[s]);
+        io.pin[s] = nullptr;
+        io.slot_done[s] = nullptr;
+    }
+    if (io.copy_stream) (void)hipStreamDestroy(io.copy_stream);
+    io.copy_stream = nullptr;
+    io.ring_ready = false;
+    for (int k = 0; k < HostIo::kKinds; ++k) {
+        if (io.ws[k]) (void)hipFree(io.ws[k]);
+        io.ws[k] = nullptr;
+        io.ws_bytes[k] = 0;
+    }
+}
+
+// Host columns -> freshly allocated device columns, all of one call together.
+struct UploadJob {
+    DevBuf *dst;
+    const void *src;
+    size_t bytes;
+    const char *what;
+};
+
+int upload_columns(pgt_ctx *ctx, UploadJob *jobs, int n_jobs, ApiTrace &trace) {
+    size_t total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (int rc = jobs[j].dst->alloc(ctx, jobs[j].bytes, jobs[j].what)) return rc;
+        total += jobs[j].bytes;
+    }
+    trace.lap("alloc columns");
+    const char *mode = std::getenv("PGT_UPLOAD");  // "plain": hipMemcpy from the caller's pageable memory, column after column
+    if (total < 4 * HostIo::kChunk || (mode && std::strcmp(mode, "plain") == 0)) {
+        for (int j = 0; j < n_jobs; ++j)
+            if (jobs[j].bytes)
+                if (int rc = hip_check(ctx, hipMemcpy(jobs[j].dst->p, jobs[j].src, jobs[j].bytes, hipMemcpyHostToDevice), jobs[j].what)) return rc;
+        trace.lap("upload (hipMemcpy)", total);
+        return PGT_OK;
+    }
+    if (int rc = ring_prepare(ctx)) return rc;
+    trace.lap("staging ring");
+    struct Piece {
+        char *dst;
+        const char *src;
+        size_t bytes;
+    };
+    HostIo &io = ctx->io;
+    std::vector<Piece> pieces;
+    for (int j = 0; j < n_jobs; ++j)
+        for (size_t off = 0; off < jobs[j].bytes; off += io.chunk)
+            pieces.push_back({static_cast<char *>(jobs[j].dst->p) + off, static_cast<const char *>(jobs[j].src) + off,
+                              std::min(io.chunk, jobs[j].bytes - off)});
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};  // a hipError_t, first one wins
+    const int device = ctx->device;
+    auto worker = [&](int w) {
+        if (hipSetDevice(device) != hipSuccess) { int z = 0; failed.compare_exchange_strong(z, (int)hipErrorInvalidDevice); return; }
+        bool used[2] = {false, false};
+        for (int turn = 0;; turn ^= 1) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pieces.size() || failed.load()) break;
+            const int s = 2 * w + turn;
+            hipError_t e = used[turn] ? hipEventSynchronize(io.slot_done[s]) : hipSuccess;  // the DMA that last read this slot
+            if (e == hipSuccess) {
+                std::memcpy(io.pin[s], pieces[i].src, pieces[i].bytes);
+                e = hipMemcpyAsync(pieces[i].dst, io.pin[s], pieces[i].bytes, hipMemcpyHostToDevice, io.copy_stream);
+            }
+            if (e == hipSuccess) e = hipEventRecord(io.slot_done[s], io.copy_stream);
+            used[turn] = true;
+            if (e != hipSuccess) { int z = 0; failed.compare_exchange_strong(z, (int)e); break; }
+        }
+    };
+    std::vector<std::thread> th;
+    const int n_workers = (int)std::min<size_t>((size_t)io.workers, pieces.size());
+    for (int w = 1; w < n_workers; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : th) t.join();
+    const hipError_t sync = hipStreamSynchronize(io.copy_stream);
+    if (failed.load()) return hip_check(ctx, (hipError_t)failed.load(), "upload columns");
+    if (int rc = hip_check(ctx, sync, "upload columns: synchronize")) return rc;
+    trace.lap("upload (ring)", total);
+    return PGT_OK;
+}
 
 // The three hints of a host table (pgt_table_hints): longest window; typical (median) length and typical step = median
 // distance between consecutive window starts, both over a sample from the middle of the table (chromosome boundaries and
@@ -214,9 +369,29 @@ pgt_ctx *pgt_open(int device) {
 
 void pgt_close(pgt_ctx *ctx) {
     if (!ctx) return;
+    int saved = -1;
+    const bool sw = hipGetDevice(&saved) == hipSuccess && saved != ctx->device && hipSetDevice(ctx->device) == hipSuccess;
+    host_io_release(ctx);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (sw) (void)hipSetDevice(saved);
     delete ctx;
+}
+
+int pgt_prepare_host_io(pgt_ctx *ctx) {
+    PGT_USE_DEVICE(ctx);
+    if (int rc = ring_prepare(ctx)) return rc;
+    // The FIRST copy of a process in each direction and flavour pays for the runtime's own set-up (its DMA queues and staging
+    // buffers: ~85 ms for the first host-to-device copy whatever its size, ~5 ms for the first small pageable one;
+    // tools/probes/host_api_probe.py) — pay it here, beside the caller's parse, with 64 KiB instead of inside the first reduce.
+    HostIo &io = ctx->io;
+    void *scratch = nullptr;
+    if (int rc = workspace(ctx, HostIo::kWin, 65536, &scratch)) return rc;
+    std::vector<char> pageable(65536, 0);
+    if (int rc = hip_check(ctx, hipMemcpyAsync(scratch, io.pin[0], 65536, hipMemcpyHostToDevice, io.copy_stream), "host io warm-up")) return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(io.copy_stream), "host io warm-up")) return rc;
+    if (int rc = hip_check(ctx, hipMemcpy(scratch, pageable.data(), pageable.size(), hipMemcpyHostToDevice), "host io warm-up")) return rc;
+    return hip_check(ctx, hipMemcpy(pageable.data(), scratch, pageable.size(), hipMemcpyDeviceToHost), "host io warm-up");
 }
 
 const char *pgt_last_error(const pgt_ctx *ctx) {
@@ -520,33 +695,61 @@ int pgt_dev_copy(pgt_ctx *dst_ctx, void *dst, pgt_ctx *src_ctx, const void *src,
 
 /* ---------------- host-buffer entry points ---------------- */
 
+extern "C++" {
+namespace {
+
+// What every *_cols entry point does around its device call: window table up (cached workspace), rows and tree from the
+// cached workspace, kernels, rows down.  `run` gets (device windows, device rows, tree, tree bytes, device total or NULL).
+template <class Row, class Run>
+int reduce_with_workspace(pgt_ctx *ctx, const char *who, int stat, uint64_t n, const pgt_win *win, uint64_t n_win, Row *out, size_t out_bytes,
+                          pgt_dxy_total *tot, Run run) {
+    ApiTrace trace(who);
+    if (int rc = room_check(ctx, who, n_win, sizeof(Row), out_bytes)) return rc;
+    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
+    const HintScope hint(ctx, win, n_win);
+    void *dwin = nullptr, *dout = nullptr, *dtree = nullptr, *dtot = nullptr;
+    const size_t tb = pgt_tree_bytes(stat, n);
+    if (int rc = workspace(ctx, HostIo::kWin, n_win * sizeof(pgt_win), &dwin)) return rc;
+    if (int rc = workspace(ctx, HostIo::kRows, n_win * sizeof(Row), &dout)) return rc;
+    if (int rc = workspace(ctx, HostIo::kTree, tb, &dtree)) return rc;
+    if (tot)
+        if (int rc = workspace(ctx, HostIo::kTot, sizeof(pgt_dxy_total), &dtot)) return rc;
+    trace.lap("workspace");
+    if (n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(dwin, win, n_win * sizeof(pgt_win), hipMemcpyHostToDevice), "upload windows")) return rc;
+    trace.lap("upload windows", n_win * sizeof(pgt_win));
+    if (int rc = run(static_cast<const pgt_win *>(dwin), static_cast<Row *>(dout), dtree, tb, static_cast<pgt_dxy_total *>(dtot))) return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "kernels")) return rc;
+    trace.lap("kernels");
+    if (n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(out, dout, n_win * sizeof(Row), hipMemcpyDeviceToHost), "download rows")) return rc;
+    if (tot)
+        if (int rc = hip_check(ctx, hipMemcpy(tot, dtot, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total")) return rc;
+    trace.lap("download rows", n_win * sizeof(Row));
+    return PGT_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
 int pgt_extreme_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_score, uint64_t n, int mode, double cutoff,
                             const pgt_win *win, uint64_t n_win, pgt_ext_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce_cols: NULL argument");
-    if (int rc = room_check(ctx, "pgt_extreme_reduce_cols", n_win, sizeof(pgt_ext_row), out_bytes)) return rc;
-    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
-    const HintScope hint(ctx, win, n_win);
-    DevBuf dwin, dout, dtree;
-    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
-    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_ext_row), "alloc rows")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_EXT, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_extreme_reduce_dev(ctx, d_pos, d_score, n, mode, cutoff, static_cast<pgt_win *>(dwin.p), n_win,
-                                        static_cast<pgt_ext_row *>(dout.p), n_win * sizeof(pgt_ext_row), dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "extreme kernels")) return rc;
-    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_ext_row), hipMemcpyDeviceToHost), "download rows");
-    return PGT_OK;
+    return reduce_with_workspace<pgt_ext_row>(ctx, "pgt_extreme_reduce_cols", PGT_STAT_EXT, n, win, n_win, out, out_bytes, nullptr,
+        [&](const pgt_win *dw, pgt_ext_row *dr, void *tree, size_t tb, pgt_dxy_total *) {
+            return pgt_extreme_reduce_dev(ctx, d_pos, d_score, n, mode, cutoff, dw, n_win, dr, n_win * sizeof(pgt_ext_row), tree, tb, nullptr);
+        });
 }
 
 int pgt_extreme_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *score, uint64_t n, int mode, double cutoff,
                        const pgt_win *win, uint64_t n_win, pgt_ext_row *out) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !score)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_extreme_reduce: NULL argument");
+    ApiTrace trace("pgt_extreme_reduce");
     DevBuf dpos, ds;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = ds.upload(ctx, score, n * sizeof(double), "upload scores")) return rc;
+    UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&ds, score, n * sizeof(double), "upload scores"}};
+    if (int rc = upload_columns(ctx, jobs, 2, trace)) return rc;
     return pgt_extreme_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(ds.p), n, mode, cutoff, win, n_win, out,
                                    (size_t)n_win * sizeof(pgt_ext_row));
 }
@@ -557,30 +760,21 @@ int pgt_fst_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_a, 
                         const pgt_win *win, uint64_t n_win, pgt_fst_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_a || !d_b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
-    if (int rc = room_check(ctx, "pgt_fst_reduce_cols", n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
-    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
-    const HintScope hint(ctx, win, n_win);
-    DevBuf dwin, dout, dtree;
-    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
-    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_fst_reduce_dev(ctx, d_pos, d_a, d_b, n, static_cast<pgt_win *>(dwin.p), n_win,
-                                    static_cast<pgt_fst_row *>(dout.p), n_win * sizeof(pgt_fst_row), dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
-    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
-    return PGT_OK;
+    return reduce_with_workspace<pgt_fst_row>(ctx, "pgt_fst_reduce_cols", PGT_STAT_FST, n, win, n_win, out, out_bytes, nullptr,
+        [&](const pgt_win *dw, pgt_fst_row *dr, void *tree, size_t tb, pgt_dxy_total *) {
+            return pgt_fst_reduce_dev(ctx, d_pos, d_a, d_b, n, dw, n_win, dr, n_win * sizeof(pgt_fst_row), tree, tb, nullptr);
+        });
 }
 
 int pgt_fst_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n,
                    const pgt_win *win, uint64_t n_win, pgt_fst_row *out) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !a || !b)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce: NULL argument");
+    ApiTrace trace("pgt_fst_reduce");
     DevBuf dpos, da, db;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
-    if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+    UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&da, a, n * sizeof(double), "upload a"},
+                        {&db, b, n * sizeof(double), "upload b"}};
+    if (int rc = upload_columns(ctx, jobs, 3, trace)) return rc;
     return pgt_fst_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(da.p), static_cast<double *>(db.p), n,
                                win, n_win, out, n_win * sizeof(pgt_fst_row));
 }
@@ -589,29 +783,20 @@ int pgt_het_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const int8_t *d_g, 
                         uint64_t n_win, pgt_het_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
-    if (int rc = room_check(ctx, "pgt_het_reduce_cols", n_win, sizeof(pgt_het_row), out_bytes)) return rc;
-    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
-    const HintScope hint(ctx, win, n_win);
-    DevBuf dwin, dout, dtree;
-    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
-    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_het_reduce_dev(ctx, d_pos, d_g, n, static_cast<pgt_win *>(dwin.p), n_win, static_cast<pgt_het_row *>(dout.p),
-                                    n_win * sizeof(pgt_het_row), dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
-    if (n_win) return hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
-    return PGT_OK;
+    return reduce_with_workspace<pgt_het_row>(ctx, "pgt_het_reduce_cols", PGT_STAT_HET, n, win, n_win, out, out_bytes, nullptr,
+        [&](const pgt_win *dw, pgt_het_row *dr, void *tree, size_t tb, pgt_dxy_total *) {
+            return pgt_het_reduce_dev(ctx, d_pos, d_g, n, dw, n_win, dr, n_win * sizeof(pgt_het_row), tree, tb, nullptr);
+        });
 }
 
 int pgt_het_reduce(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *win,
                    uint64_t n_win, pgt_het_row *out) {
     PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !g)) || (n_win && (!win || !out))) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce: NULL argument");
+    ApiTrace trace("pgt_het_reduce");
     DevBuf dpos, dg;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+    UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&dg, g, n * sizeof(int8_t), "upload genotypes"}};
+    if (int rc = upload_columns(ctx, jobs, 2, trace)) return rc;
     return pgt_het_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<int8_t *>(dg.p), n, win, n_win, out,
                                n_win * sizeof(pgt_het_row));
 }
@@ -622,24 +807,11 @@ int pgt_dxy_reduce_cols(pgt_ctx *ctx, const uint32_t *d_pos, const double *d_p1,
     PGT_USE_DEVICE(ctx);
     if ((n && (!d_pos || !d_p1 || !d_p2 || !d_n1 || !d_n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
-    if (int rc = room_check(ctx, "pgt_dxy_reduce_cols", n_win, sizeof(pgt_dxy_row), out_bytes)) return rc;
-    if (int rc = check_windows_host(ctx, win, n_win, n, true)) return rc;
-    const HintScope hint(ctx, win, n_win);
-    DevBuf dwin, dout, dtot, dtree;
-    if (int rc = dwin.upload(ctx, win, n_win * sizeof(pgt_win), "upload windows")) return rc;
-    if (int rc = dout.alloc(ctx, n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
-    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_dxy_reduce_dev(ctx, d_pos, d_p1, d_p2, d_n1, d_n2, n, minind, static_cast<pgt_win *>(dwin.p), n_win,
-                                    static_cast<pgt_dxy_row *>(dout.p), n_win * sizeof(pgt_dxy_row),
-                                    tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
-    if (n_win)
-        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
-    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
-    return PGT_OK;
+    return reduce_with_workspace<pgt_dxy_row>(ctx, "pgt_dxy_reduce_cols", PGT_STAT_DXY, n, win, n_win, out, out_bytes, tot,
+        [&](const pgt_win *dw, pgt_dxy_row *dr, void *tree, size_t tb, pgt_dxy_total *dtot) {
+            return pgt_dxy_reduce_dev(ctx, d_pos, d_p1, d_p2, d_n1, d_n2, n, minind, dw, n_win, dr, n_win * sizeof(pgt_dxy_row), dtot, tree, tb,
+                                      nullptr);
+        });
 }
 
 int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1,
@@ -648,12 +820,12 @@ int pgt_dxy_reduce(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const do
     PGT_USE_DEVICE(ctx);
     if ((n && (!pos || !p1 || !p2 || !n1 || !n2)) || (n_win && (!win || !out)))
         return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce: NULL argument");
+    ApiTrace trace("pgt_dxy_reduce");
     DevBuf dpos, d1, d2, dn1, dn2;
-    if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-    if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;
-    if (int rc = d2.upload(ctx, p2, n * sizeof(double), "upload p2")) return rc;
-    if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
-    if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
+    UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&d1, p1, n * sizeof(double), "upload p1"},
+                        {&d2, p2, n * sizeof(double), "upload p2"}, {&dn1, n1, n * sizeof(int32_t), "upload n1"},
+                        {&dn2, n2, n * sizeof(int32_t), "upload n2"}};
+    if (int rc = upload_columns(ctx, jobs, 5, trace)) return rc;
     return pgt_dxy_reduce_cols(ctx, static_cast<uint32_t *>(dpos.p), static_cast<double *>(d1.p), static_cast<double *>(d2.p),
                                static_cast<int32_t *>(dn1.p), static_cast<int32_t *>(dn2.p), n, minind, win, n_win, out,
                                n_win * sizeof(pgt_dxy_row), tot);
@@ -685,7 +857,8 @@ int pgt_wintab_sites(pgt_ctx *ctx, const uint64_t *run_len, size_t n_runs, uint3
     tab->first[n_runs] = count;
     if (count) {
         DevBuf dplan;
-        if (int rc = dplan.upload(ctx, plan.data(), plan.size() * sizeof(RunPlan), "upload window plan")) return rc;
+        if (int rc = dplan.alloc(ctx, plan.size() * sizeof(RunPlan), "alloc window plan")) return rc;
+        if (int rc = hip_check(ctx, hipMemcpy(dplan.p, plan.data(), plan.size() * sizeof(RunPlan), hipMemcpyHostToDevice), "upload window plan")) return rc;
         void *p = nullptr;
         if (int rc = hip_check(ctx, hipMalloc(&p, count * sizeof(pgt_win)), "alloc window table")) return rc;
         tab->d_win = static_cast<pgt_win *>(p);
@@ -731,6 +904,32 @@ int tab_check(pgt_ctx *ctx, const pgt_wintab *tab, const void *out, const char *
 }
 }  // namespace
 
+extern "C++" {
+namespace {
+// the *_tab entry points: table already on the device; rows and tree from the cached workspace
+template <class Row, class Run>
+int reduce_tab(pgt_ctx *ctx, const char *who, int stat, uint64_t n, const pgt_wintab *tab, Row *out, pgt_dxy_total *tot, ApiTrace &trace, Run run) {
+    const TabHints hint(ctx, tab);
+    void *dout = nullptr, *dtree = nullptr, *dtot = nullptr;
+    const size_t tb = pgt_tree_bytes(stat, n);
+    if (int rc = workspace(ctx, HostIo::kRows, tab->n_win * sizeof(Row), &dout)) return rc;
+    if (int rc = workspace(ctx, HostIo::kTree, tb, &dtree)) return rc;
+    if (tot)
+        if (int rc = workspace(ctx, HostIo::kTot, sizeof(pgt_dxy_total), &dtot)) return rc;
+    trace.lap("workspace");
+    if (int rc = run(static_cast<Row *>(dout), dtree, tb, static_cast<pgt_dxy_total *>(dtot))) return rc;
+    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), who)) return rc;
+    trace.lap("kernels");
+    if (tab->n_win)
+        if (int rc = hip_check(ctx, hipMemcpy(out, dout, tab->n_win * sizeof(Row), hipMemcpyDeviceToHost), "download rows")) return rc;
+    if (tot)
+        if (int rc = hip_check(ctx, hipMemcpy(tot, dtot, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total")) return rc;
+    trace.lap("download rows", tab->n_win * sizeof(Row));
+    return PGT_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const double *b, uint64_t n, int cols_on_device,
                        const pgt_wintab *tab, pgt_fst_row *out, size_t out_bytes) {
     PGT_USE_DEVICE(ctx);
@@ -738,22 +937,18 @@ int pgt_fst_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *a, const
     if (int rc = room_check(ctx, "pgt_fst_reduce_tab", tab->n_win, sizeof(pgt_fst_row), out_bytes)) return rc;
     if (n && (!pos || !a || !b)) return ctx_fail(ctx, PGT_EARG, "pgt_fst_reduce_tab: NULL argument");
     if (tab->n_win == 0) return PGT_OK;
-    DevBuf dpos, da, db, dout, dtree;
+    ApiTrace trace("pgt_fst_reduce_tab");
+    DevBuf dpos, da, db;
     if (!cols_on_device) {
-        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-        if (int rc = da.upload(ctx, a, n * sizeof(double), "upload a")) return rc;
-        if (int rc = db.upload(ctx, b, n * sizeof(double), "upload b")) return rc;
+        UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&da, a, n * sizeof(double), "upload a"},
+                            {&db, b, n * sizeof(double), "upload b"}};
+        if (int rc = upload_columns(ctx, jobs, 3, trace)) return rc;
         pos = static_cast<uint32_t *>(dpos.p); a = static_cast<double *>(da.p); b = static_cast<double *>(db.p);
     }
-    const TabHints hint(ctx, tab);
-    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_fst_row), "alloc rows")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_FST, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_fst_reduce_dev(ctx, pos, a, b, n, tab->d_win, tab->n_win, static_cast<pgt_fst_row *>(dout.p),
-                                    tab->n_win * sizeof(pgt_fst_row), dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "fst kernels")) return rc;
-    return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_fst_row), hipMemcpyDeviceToHost), "download rows");
+    return reduce_tab<pgt_fst_row>(ctx, "fst kernels", PGT_STAT_FST, n, tab, out, nullptr, trace,
+        [&](pgt_fst_row *dr, void *tree, size_t tb, pgt_dxy_total *) {
+            return pgt_fst_reduce_dev(ctx, pos, a, b, n, tab->d_win, tab->n_win, dr, tab->n_win * sizeof(pgt_fst_row), tree, tb, nullptr);
+        });
 }
 
 int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint64_t n, int cols_on_device, const pgt_wintab *tab,
@@ -763,21 +958,17 @@ int pgt_het_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const int8_t *g, uint6
     if (int rc = room_check(ctx, "pgt_het_reduce_tab", tab->n_win, sizeof(pgt_het_row), out_bytes)) return rc;
     if (n && (!pos || !g)) return ctx_fail(ctx, PGT_EARG, "pgt_het_reduce_tab: NULL argument");
     if (tab->n_win == 0) return PGT_OK;
-    DevBuf dpos, dg, dout, dtree;
+    ApiTrace trace("pgt_het_reduce_tab");
+    DevBuf dpos, dg;
     if (!cols_on_device) {
-        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-        if (int rc = dg.upload(ctx, g, n * sizeof(int8_t), "upload genotypes")) return rc;
+        UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&dg, g, n * sizeof(int8_t), "upload genotypes"}};
+        if (int rc = upload_columns(ctx, jobs, 2, trace)) return rc;
         pos = static_cast<uint32_t *>(dpos.p); g = static_cast<int8_t *>(dg.p);
     }
-    const TabHints hint(ctx, tab);
-    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_het_row), "alloc rows")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_HET, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_het_reduce_dev(ctx, pos, g, n, tab->d_win, tab->n_win, static_cast<pgt_het_row *>(dout.p),
-                                    tab->n_win * sizeof(pgt_het_row), dtree.p, tb, nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "het kernels")) return rc;
-    return hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_het_row), hipMemcpyDeviceToHost), "download rows");
+    return reduce_tab<pgt_het_row>(ctx, "het kernels", PGT_STAT_HET, n, tab, out, nullptr, trace,
+        [&](pgt_het_row *dr, void *tree, size_t tb, pgt_dxy_total *) {
+            return pgt_het_reduce_dev(ctx, pos, g, n, tab->d_win, tab->n_win, dr, tab->n_win * sizeof(pgt_het_row), tree, tb, nullptr);
+        });
 }
 
 int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, const double *p2, const int32_t *n1, const int32_t *n2,
@@ -787,30 +978,21 @@ int pgt_dxy_reduce_tab(pgt_ctx *ctx, const uint32_t *pos, const double *p1, cons
     if (int rc = tab_check(ctx, tab, out, "pgt_dxy_reduce_tab")) return rc;
     if (int rc = room_check(ctx, "pgt_dxy_reduce_tab", tab->n_win, sizeof(pgt_dxy_row), out_bytes)) return rc;
     if (n && (!pos || !p1 || !p2 || !n1 || !n2)) return ctx_fail(ctx, PGT_EARG, "pgt_dxy_reduce_tab: NULL argument");
-    DevBuf dpos, d1, d2, dn1, dn2, dout, dtot, dtree;
+    ApiTrace trace("pgt_dxy_reduce_tab");
+    DevBuf dpos, d1, d2, dn1, dn2;
     if (!cols_on_device) {
-        if (int rc = dpos.upload(ctx, pos, n * sizeof(uint32_t), "upload pos")) return rc;
-        if (int rc = d1.upload(ctx, p1, n * sizeof(double), "upload p1")) return rc;
-        if (int rc = d2.upload(ctx, p2, n * sizeof(double), "upload p2")) return rc;
-        if (int rc = dn1.upload(ctx, n1, n * sizeof(int32_t), "upload n1")) return rc;
-        if (int rc = dn2.upload(ctx, n2, n * sizeof(int32_t), "upload n2")) return rc;
+        UploadJob jobs[] = {{&dpos, pos, n * sizeof(uint32_t), "upload pos"}, {&d1, p1, n * sizeof(double), "upload p1"},
+                            {&d2, p2, n * sizeof(double), "upload p2"}, {&dn1, n1, n * sizeof(int32_t), "upload n1"},
+                            {&dn2, n2, n * sizeof(int32_t), "upload n2"}};
+        if (int rc = upload_columns(ctx, jobs, 5, trace)) return rc;
         pos = static_cast<uint32_t *>(dpos.p); p1 = static_cast<double *>(d1.p); p2 = static_cast<double *>(d2.p);
         n1 = static_cast<int32_t *>(dn1.p); n2 = static_cast<int32_t *>(dn2.p);
     }
-    const TabHints hint(ctx, tab);
-    if (int rc = dout.alloc(ctx, tab->n_win * sizeof(pgt_dxy_row), "alloc rows")) return rc;
-    if (int rc = dtot.alloc(ctx, sizeof(pgt_dxy_total), "alloc total")) return rc;
-    const size_t tb = pgt_tree_bytes(PGT_STAT_DXY, n);
-    if (int rc = dtree.alloc(ctx, tb, "alloc tree")) return rc;
-    if (int rc = pgt_dxy_reduce_dev(ctx, pos, p1, p2, n1, n2, n, minind, tab->d_win, tab->n_win, static_cast<pgt_dxy_row *>(dout.p),
-                                    tab->n_win * sizeof(pgt_dxy_row), tot ? static_cast<pgt_dxy_total *>(dtot.p) : nullptr, dtree.p, tb,
-                                    nullptr))
-        return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(nullptr), "dxy kernels")) return rc;
-    if (tab->n_win)
-        if (int rc = hip_check(ctx, hipMemcpy(out, dout.p, tab->n_win * sizeof(pgt_dxy_row), hipMemcpyDeviceToHost), "download rows")) return rc;
-    if (tot) return hip_check(ctx, hipMemcpy(tot, dtot.p, sizeof(pgt_dxy_total), hipMemcpyDeviceToHost), "download total");
-    return PGT_OK;
+    return reduce_tab<pgt_dxy_row>(ctx, "dxy kernels", PGT_STAT_DXY, n, tab, out, tot, trace,
+        [&](pgt_dxy_row *dr, void *tree, size_t tb, pgt_dxy_total *dtot) {
+            return pgt_dxy_reduce_dev(ctx, pos, p1, p2, n1, n2, n, minind, tab->d_win, tab->n_win, dr, tab->n_win * sizeof(pgt_dxy_row), dtot, tree,
+                                      tb, nullptr);
+        });
 }
 
 /* copy of a device column of an ingest object to the host (dxyWindow's site synchronisation and bp-window

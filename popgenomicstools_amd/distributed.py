@@ -134,11 +134,11 @@ class RowExchange:
     counts[r] = rows rank r produces per scan (tables * windows of its shard).  With tables > 1
     (population pairs) a rank's block is table-major over ITS windows; finish() re-interleaves to
     table-major over ALL windows.  coll_device: where collective tensors live (the GPU for nccl,
-    CPU for gloo); defaults to `device`.
+    CPU for gloo); defaults to `device`.  gather_to_self: with ONE rank, run the gather anyway (default: rows stay local).
     """
 
     def __init__(self, ctx, counts, row_bytes: int, device, dst: int = 0, group=None, mode: str = "gather",
-                 tables: int = 1, coll_device=None):
+                 tables: int = 1, coll_device=None, gather_to_self: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.ctx = torch, dist, ctx
@@ -155,7 +155,12 @@ class RowExchange:
         self.total = _align(self.offsets[-1] + self.counts[-1] * self.row_bytes)
         if mode not in ("auto", "gather", "peer", "peer_or_gather", "local"):
             raise PgtError(1, f"RowExchange: unknown mode {mode!r}")
-        self.mode = "local" if self.world == 1 else ("gather" if mode == "auto" else mode)
+        # One rank has nothing to exchange ("local": the rows stay where the kernel wrote them) — unless the caller asks for the
+        # gather all the same (gather_to_self, with an initialised process group): the whole per-step machinery of the
+        # multi-GPU run (torch.distributed.gather enqueue on RCCL, event waits, two send buffers, two receive sets) then runs
+        # on a group of one rank, which is how bench.py prices it on a one-GPU box (extra.exchange_overhead).
+        to_self = gather_to_self and mode in ("auto", "gather") and dist.is_initialized()
+        self.mode = ("gather" if to_self else "local") if self.world == 1 else ("gather" if mode == "auto" else mode)
         self.buf = None       # peer: the shared row buffer (owned on dst, mapped elsewhere)
         self.peer_error = ""
         if self.mode in ("peer_or_gather", "peer"):

@@ -744,6 +744,9 @@ class DeviceOpener {
             th_.emplace_back([this, k] {
                 ctx_[k] = pgt_open(ids_[k]);
                 if (!ctx_[k]) err_[k] = pgt_last_error(nullptr);  // thread-local in the library: copy it here
+                // the pinned staging ring of the host-buffer entry points (~15 ms of hipHostMalloc): here, beside the parse,
+                // instead of inside the first reduce; a failure is not fatal (the reduce reports it if it needs the ring)
+                else (void)pgt_prepare_host_io(ctx_[k]);
             });
     }
     ~DeviceOpener() {

@@ -73,3 +73,33 @@ def test_gloo_ranks_match_single(tmp_path, world, port):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for tag in ["GLOO_OK sharded_scan", "GLOO_OK tables", "GLOO_OK empty-shard"] + (["GLOO_OK subgroup"] if world >= 3 else []):
         assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.timeout(120)
+def test_row_exchange_gathers_to_itself_on_one_rank():
+    """RowExchange(gather_to_self=True) on a group of ONE rank (gloo here, RCCL in bench.py's exchange_overhead leg): the
+    double-buffered asynchronous gather runs as it does between GPUs and delivers each scan's rows; without the flag one
+    rank keeps the 'local' mode.  In a child process: the process group is process-wide state."""
+    code = r"""
+import numpy as np, torch, torch.distributed as dist
+from popgenomicstools_amd.distributed import RowExchange
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+cpu = torch.device("cpu")
+for tables in (1, 3):
+    counts = [7 * tables]
+    assert RowExchange(None, counts, 40, cpu, tables=tables).mode == "local"
+    ex = RowExchange(None, counts, 40, cpu, tables=tables, gather_to_self=True)
+    assert ex.mode == "gather"
+    for k in range(5):
+        out = ex.begin()
+        assert out.numel() == 7 * tables * 40
+        out.copy_(torch.full((out.numel(),), k + 1, dtype=torch.uint8))
+        ex.end()
+    got = ex.finish()
+    assert got.shape == (7 * tables * 40,) and np.all(got == 5), got[:8]
+    ex.close()
+dist.destroy_process_group()
+print("SELF_GATHER_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT), timeout=100)
+    assert r.returncode == 0 and "SELF_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -5,7 +5,7 @@
 set -eu
 NAME=$1; shift || true
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-CSRC=$ROOT/popgenomicstools_amd/csrc
+CSRC=${PGT_CSRC:-$ROOT/popgenomicstools_amd/csrc}   # PGT_CSRC: a patched copy of csrc/ (one-off experiments: see profiles/r06/af8_issue_stall.md)
 OBJ=$ROOT/tools/_ab/obj
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$ROOT/include -I$CSRC $*"

@@ -71,10 +71,10 @@ def main():
         b_name = os.path.relpath(_lib.LIB_PATH, ROOT)
     ctx_b = pgt.Context(0)
     _lib._lib, _lib.LIB_PATH = None, old
-    _lib.SYMBOLS = [x for x in _lib.SYMBOLS if x != "pgt_extreme_reduce_cols"]  # added in round 4: an older build lacks it, no config here calls it
+    _lib.SYMBOLS = [x for x in _lib.SYMBOLS if x not in ("pgt_extreme_reduce_cols", "pgt_prepare_host_io")]  # added in rounds 4 / 6: an older build lacks them, no config here calls them
     import ctypes
     a_abi = ctypes.CDLL(old).pgt_abi_version()
-    assert a_abi in (4, 5), a_abi  # 4 -> 5 changed no argument list (alignment of the i32 columns, the dxy workspace size): safe to call for this tool
+    assert a_abi in (4, 5, 6), a_abi  # 4 -> 5 -> 6 changed no argument list (5: alignment of the i32 columns, the dxy workspace size; 6: pgt_prepare_host_io added): safe to call for this tool
     _lib.PGT_ABI_VERSION = a_abi
     ctx_a = pgt.Context(0)
     assert ctx_a._lib is not ctx_b._lib
