@@ -179,7 +179,31 @@ class Telemetry:
         return _Sampler(self, period_s)
 
     def describe(self) -> dict:
-        return {"source": self.source or ["none"], "pci": self.bdf, "errors": self.errors}
+        """What was read and from where, plus the card's identity (which physical GPU, its memory vendor, firmware, partition
+        modes): box-to-box differences of the same binary are larger than process-to-process ones on this pool, so a line
+        should say which card produced it."""
+        out = {"source": self.source or ["none"], "pci": self.bdf, "errors": self.errors}
+        ident = {}
+        if self.handle is not None:
+            for key, fn in (("asic", "amdsmi_get_gpu_asic_info"), ("vram", "amdsmi_get_gpu_vram_info"), ("vbios", "amdsmi_get_gpu_vbios_info"),
+                            ("board", "amdsmi_get_gpu_board_info"), ("compute_partition", "amdsmi_get_gpu_compute_partition"),
+                            ("memory_partition", "amdsmi_get_gpu_memory_partition"), ("driver", "amdsmi_get_gpu_driver_info")):
+                try:
+                    v = getattr(self.smi, fn)(self.handle)
+                    if isinstance(v, dict):
+                        v = {k: x for k, x in v.items() if isinstance(x, (int, float, str, bool)) and x not in ("N/A", "")}
+                    ident[key] = v if isinstance(v, (dict, int, float, str)) else str(v)
+                except Exception:  # noqa: BLE001
+                    pass
+        if self.card is not None:
+            for f in ("unique_id", "vbios_version", "current_compute_partition", "current_memory_partition", "mem_info_vram_total",
+                      "mem_info_vram_vendor"):
+                v = _read(os.path.join(self.card, f))
+                if v is not None:
+                    ident["sysfs_" + f] = v
+        if ident:
+            out["identity"] = ident
+        return out
 
 
 def _stats(xs):

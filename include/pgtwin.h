@@ -93,7 +93,7 @@ void pgt_close(pgt_ctx *ctx);
 const char *pgt_last_error(const pgt_ctx *ctx);
 int pgt_abi_version(void);
 /* Optional: allocate the pinned staging ring of the host-buffer entry points (pgt_*_reduce with host columns) now
- * (~15 ms of hipHostMalloc) instead of inside the first such call — the retained hosts call it on the thread that opens
+ * (~15 ms of hipHostMalloc + the runtime's one-time 30 … 60 ms set-up of the first copies of a process) instead of inside the first such call — the retained hosts call it on the thread that opens
  * the device, beside the text parse.  Replaces nothing in the reference (its calcWindow reads the caller's buffer in place,
  * fstWindow.cpp:76-83); it exists because the columns have to cross PCIe here. */
 int pgt_prepare_host_io(pgt_ctx *ctx);

@@ -171,7 +171,8 @@ def load() -> C.CDLL:
     lib.pgt_fst_reduce_tab.argtypes = [vp, vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, vp]
-    lib.pgt_prepare_host_io.argtypes = [vp]
+    if "pgt_prepare_host_io" in SYMBOLS:  # (tools/lib_ab.py drops it from the list to load a round-5 library beside the tree's)
+        lib.pgt_prepare_host_io.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -172,7 +172,7 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 // against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt): there the kernel is bound by
 // its node stores and its arithmetic, and 4 x 8 column registers cost the prefetch of the next piece.
 template <int NP, int BURST = 0>
-__global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
+__global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
     constexpr int V = Shape<NP>::kVals;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
         // WAVES START THEIR TILES AT DIFFERENT PIECES (round 5; pgt_kernels.hip: tile_rotation): the waves run in lockstep, and
         // without this all of them are at the same offset of their tiles at any moment.  Even, a multiple of the burst; the
         // partial last tile is walked from its start (its guarded loads stop at n).
-        const int rot = full ? (int)(((wave0 * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - (BURST > 0 ? BURST : 4))) : 0;
+        static_assert(kAfPieces == 2 || kAfPieces == 4 || kAfPieces == 8, "the walks below take a leaf's pieces two at a time, in bursts of 4");
+        const int rot = full ? (int)(((wave0 * 0x9E3779B1ull) >> 13) & (uint64_t)(kRadix - (kAfPieces > 4 ? kAfPieces : 4))) : 0;
         double l2acc = 0.0;
         double vals[V];
         auto load_full = [&](double2 *dst, int j) {  // piece j of a FULL tile: one 16-byte nt load per lane and column
@@ -236,10 +237,11 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
                         double fx[NP], fy[NP];
 #pragma unroll
                         for (int k = 0; k < NP; ++k) { fx[k] = d[k][u].x; fy[k] = d[k][u].y; }
-                        if ((u & (kAfPieces - 1)) == 0) af_accumulate<NP, true>(vals, fx);  // a leaf's first site starts the sums
+                        const int ph = (i0 + u) & (kAfPieces - 1);  // the piece's place in its leaf (i0 and j0 agree modulo the leaf: see `rot`)
+                        if (ph == 0) af_accumulate<NP, true>(vals, fx);  // a leaf's first site starts the sums
                         else af_accumulate<NP>(vals, fx);
                         af_accumulate<NP>(vals, fy);
-                        if ((u & (kAfPieces - 1)) == kAfPieces - 1) {
+                        if (ph == kAfPieces - 1) {
                             rs_steps<V, 0>(vals, lane);
                             if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];
                         }
@@ -254,14 +256,25 @@ __global__ __launch_bounds__(256) void af_build_kernel(AfCols cols, uint64_t n, 
             double2 pa[NP], pb[NP];
             load_full(pa, rot);
 #pragma unroll 1
-            for (int i = 0; i < kRadix; i += kAfPieces) {
-                const int j = (i + rot) & (kRadix - 1);  // rot is even: a leaf's two pieces stay together
+            for (int i = 0; i < kRadix; i += kAfPieces) {  // one leaf per turn: kAfPieces pieces, two at a time
+                const int j = (i + rot) & (kRadix - 1);  // rot is a multiple of the leaf's pieces: they stay together
                 load_full(pb, j + 1);
-                reduce_piece(std::true_type{}, pa);
-                if (i + kAfPieces < kRadix) load_full(pa, (j + kAfPieces) & (kRadix - 1));
+                reduce_piece(std::true_type{}, pa);  // a leaf's first site starts the sums
+                if (i + 2 < kRadix) load_full(pa, (j + 2) & (kRadix - 1));
                 reduce_piece(std::false_type{}, pb);
+                auto next_pair = [&](int h) {
+                    load_full(pb, j + h + 1);
+                    reduce_piece(std::false_type{}, pa);
+                    if (i + h + 2 < kRadix) load_full(pa, (j + h + 2) & (kRadix - 1));
+                    reduce_piece(std::false_type{}, pb);
+                };
+                if constexpr (kAfPieces == 4) next_pair(2);  // straight-line: rolled, the allocator wants 280 registers for it
+                if constexpr (kAfPieces > 4) {
+#pragma unroll 1
+                    for (int h = 2; h < kAfPieces; h += 2) next_pair(h);  // (unrolled, a whole leaf's loads are hoisted: 408 registers at 8 pieces)
+                }
                 rs_steps<V, 0>(vals, lane);  // the leaf is complete: one reduce-scatter per leaf
-                if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];  // node j/2 of the wave's LDS stage: V consecutive doubles (conflict-free)
+                if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];  // node j/kAfPieces of the wave's LDS stage: V consecutive doubles (conflict-free)
             }
         }
         if (!full) {  // the last, partial level-2 tile (one wave of the grid, once): guarded loads, no prefetch; f = 0 contributes nothing
@@ -341,12 +354,26 @@ __global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32
         double acc[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = 0.0;
+        // A window's answer is a chain of dependent memory round trips (its table entry, ragged sites left and right, ragged
+        // nodes left and right of every level, the top level, its coordinates), ~1.5 us each under load: until round 6 there
+        // were up to 13 of them — every 64 ragged sites were a trip of their own.  Now a side's ragged sites are REQUESTED TOGETHER,
+        // before the first addition (up to kAfLeaf / 64 strides in flight at once), which leaves 7.  (Both ragged sides of a node
+        // level in flight together would save one more trip per level and cost 72 more registers: 320, one wave per SIMD.)
+        // Each lane still adds its items in the order it did (left before right, strides ascending): rows bit for bit those of
+        // the stride-by-stride form.
+        constexpr int kStrides = kAfLeaf / kWave < 8 ? kAfLeaf / kWave : 8;  // a ragged side holds fewer than kAfLeaf sites; 8 strides = 128 registers at 8 populations
         auto sum_sites = [&](uint64_t from, uint64_t to) {
-            for (uint64_t i = from + lane; i < to; i += kWave) {
-                double f[NP];
+            for (uint64_t at = from; at < to; at += (uint64_t)kStrides * kWave) {
+                double f[kStrides][NP];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) f[k] = cols.f[k][i];
-                af_accumulate<NP>(acc, f);
+                for (int t = 0; t < kStrides; ++t) {
+                    const uint64_t i = at + (uint64_t)t * kWave + lane;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) f[t][k] = i < to ? cols.f[k][i] : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < kStrides; ++t)
+                    if (at + (uint64_t)t * kWave + lane < to) af_accumulate<NP>(acc, f[t]);
             }
         };
         auto sum_nodes = [&](int level, uint64_t from, uint64_t to) {

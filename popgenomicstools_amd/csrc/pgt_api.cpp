@@ -17,7 +17,7 @@
 #include "pgt_internal.h"
 
 // Host I/O of the host-buffer entry points (pgt_fst_reduce & co., what INTEGRATION.md binds), kept per context:
-//  * a PINNED STAGING RING for the column uploads: `workers` host threads copy 8-MiB pieces of the caller's pageable columns
+//  * a PINNED STAGING RING for the column uploads: `workers` host threads copy 16-MiB pieces of the caller's pageable columns
 //    into their own two pinned slots and queue the DMA of each piece themselves (hipMemcpyAsync on one copy stream), so the
 //    host-side memcpy of piece k+1 overlaps the DMA of piece k and nothing of the caller's memory has to be page-locked.
 //    A plain hipMemcpy from pageable memory lets the runtime pin the caller's pages first: 0.45 ms/MiB the first time a
@@ -28,12 +28,18 @@
 struct HostIo {
     static constexpr int kMaxWorkers = 16, kSlots = 2 * kMaxWorkers;
     static constexpr size_t kChunk = (size_t)8 << 20;  // threshold for taking the ring at all: 4 of these
-    int workers = 4;                   // PGT_UPLOAD_WORKERS (1 … 16)
-    size_t chunk = (size_t)8 << 20;    // PGT_UPLOAD_CHUNK_MIB (1 … 64); two slots of this size per worker
+    // geometry: profiles/r06/host_api_ring_geometry_sweep.txt (2 GB of fst columns, steady state): 16-MiB pieces 38.8 ms = 51.5 GB/s
+    // with 2 … 12 workers alike, 8 MiB 40.5, 4 MiB 44.5, 2 MiB 52; a plain hipMemcpy of the SAME buffer again 36.5 (the runtime
+    // caches its pin of the caller's pages; a first call pays 85 ms more)
+    // What the ring costs to set up (tools/probes/first_use_probe.cpp): hipHostMalloc 15 ms per 64 MiB; a stream of its own 18 ms
+    // (it would only buy what nobody needs: the kernels that follow wait for the columns anyway) — so: the NULL stream, and the
+    // smallest geometry that still runs at the link's rate.
+    int workers = 2;                   // PGT_UPLOAD_WORKERS (1 … 16)
+    size_t chunk = (size_t)16 << 20;   // PGT_UPLOAD_CHUNK_MIB (1 … 64); two slots of this size per worker: 64 MiB pinned
     bool ring_ready = false;
     char *pin[kSlots] = {};
     hipEvent_t slot_done[kSlots] = {};
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // the NULL stream (see above)
     enum { kWin = 0, kRows, kTree, kTot, kKinds };
     void *ws[kKinds] = {};
     size_t ws_bytes[kKinds] = {};
@@ -120,7 +126,6 @@ int ring_prepare(pgt_ctx *ctx) {
     if (io.ring_ready) return PGT_OK;
     if (const char *e = std::getenv("PGT_UPLOAD_WORKERS")) io.workers = std::min(std::max(std::atoi(e), 1), (int)HostIo::kMaxWorkers);
     if (const char *e = std::getenv("PGT_UPLOAD_CHUNK_MIB")) io.chunk = (size_t)std::min(std::max(std::atoi(e), 1), 64) << 20;
-    if (int rc = hip_check(ctx, hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking), "upload ring: hipStreamCreate")) return rc;
     for (int s = 0; s < 2 * io.workers; ++s) {
         if (int rc = hip_check(ctx, hipHostMalloc(reinterpret_cast<void **>(&io.pin[s]), io.chunk, hipHostMallocDefault), "upload ring: hipHostMalloc")) return rc;
         if (int rc = hip_check(ctx, hipEventCreateWithFlags(&io.slot_done[s], hipEventDisableTiming), "upload ring: hipEventCreate")) return rc;
@@ -137,8 +142,6 @@ void host_io_release(pgt_ctx *ctx) {
         io.pin[s] = nullptr;
         io.slot_done[s] = nullptr;
     }
-    if (io.copy_stream) (void)hipStreamDestroy(io.copy_stream);
-    io.copy_stream = nullptr;
     io.ring_ready = false;
     for (int k = 0; k < HostIo::kKinds; ++k) {
         if (io.ws[k]) (void)hipFree(io.ws[k]);

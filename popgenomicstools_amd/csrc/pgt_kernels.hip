@@ -169,8 +169,7 @@ struct NodeStage {
 // — a hash of the wave index, in steps of the batch size — and wraps around; a leaf's sum does not depend on when it is read
 // and lane j still keeps leaf j's, so every node is bit for bit what it was.  Interleaved A/B of the two builds in one
 // process (tools/lib_ab.py; % of the HBM peak; profiles/r05/ab_series.md, lib_ab_rotation_all_*.md): fst build 79.5 -> 82.9 and
-// 78.8 -> 82.0 at 10^8 sites, 80.3 -> 81.4 and 81.1 -> 82.3 at 10^9 (two more runs, whose files a later run overwrote, read
-// 81.3 -> 84.9 and 83.2 -> 85.7); dxy 77.5 -> 82.2 at 10^8, 83.6 -> 85.4 at 10^9; fused 79.2 -> 82.1, 82.6 -> 83.7; the AF front end
+// 78.8 -> 82.0 at 10^8 sites, 80.3 -> 81.4 and 81.1 -> 82.3 at 10^9; dxy 77.5 -> 82.2 at 10^8, 83.6 -> 85.4 at 10^9; fused 79.2 -> 82.1, 82.6 -> 83.7; the AF front end
 // +3 ... +5 points at 10^8 (pgt_af_kernels.hip); the extreme-score build unchanged by itself, but its geometry could then be
 // chosen (ext_build_launch).  A plain (4 x wave) & 63 gives the same at 10^8 sites and a point less at 10^9; a start that
 // changes from tile to tile (hash of the tile index) or differs between the two columns of a tile gains less; starts at any
@@ -342,8 +341,7 @@ __device__ __forceinline__ void dxy_acc(NodeDxy &acc, double v) {  // dxyWindow.
 // (0, 1) of the pair — pair site 128h + 2l + q, i.e. count lane 32h + (l >> 1), component 2(l & 1) + q — picks its two bits
 // from the masks.  Integer-exact, the f64 arithmetic is untouched: rows bit for bit those of the 8-byte form.
 // MEASURED (interleaved A/B of the two builds in one process, profiles/r05/lib_ab_v1_1e8.md, ab_series.md `v1_pairs`): a TIE —
-// dxy 80.9 -> 79.8 and 80.1 -> 79.9 % at 10^8 sites, 80.9 -> 81.0 at 10^9 (81.3 -> 82.6 in a run whose file was overwritten);
-// fused 80.3 -> 80.8 at 10^8.  The guide's 0.54-0.70x for
+// dxy 80.9 -> 79.8 and 80.1 -> 79.9 % at 10^8 sites, 80.9 -> 81.0 at 10^9; fused 80.3 -> 80.8 at 10^8.  The guide's 0.54-0.70x for
 // 8-byte nt accesses does not bind here: the kernel waits on HBM, not on the load unit.  Kept because every byte of every
 // build kernel is now read by a 16-byte load, the one width rocprofv3's FETCH_SIZE is calibrated for (profiles/r05).
 struct PairPred { unsigned long long m0, m1, m2, m3; };  // four scalars (an array of them lands in scratch)

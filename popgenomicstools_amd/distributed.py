@@ -265,8 +265,20 @@ class RowExchange:
     def begin(self):
         if self.mode == "peer":
             return self.my_out
-        if self.pending[self.k] is not None:  # the gather that last read this buffer must be done
-            self.pending[self.k].wait()
+        w = self.pending[self.k]
+        if w is not None:  # the gather that last read this buffer must be done
+            # It was issued two scans ago: almost always it HAS completed, and then nothing needs to be put into the launch
+            # stream.  A stream-level wait costs more than it looks — a barrier packet in front of the build kernel keeps the
+            # build from being dispatched behind the previous query's tail: together with the event the gather itself records
+            # that was 17-19 us of idle GPU per scan (profiles/r06/exchange_trace_summary.md).
+            done = False
+            if self.coll_device.type == "cuda":  # (gloo: wait() is what reports a failed transfer, and costs nothing on the GPU)
+                try:
+                    done = bool(w.is_completed())
+                except Exception:  # noqa: BLE001 — a backend without completion queries: wait as before
+                    done = False
+            if not done:
+                w.wait()
             self.pending[self.k] = None
         return self.outs[self.k]
 
@@ -385,8 +397,10 @@ def sharded_dxy_scan(win: np.ndarray, n_sites: int, load_columns, ctx, minind: i
     block as windows of TOTAL_BLOCK sites, the rows of those blocks travel with the window rows, and `dst` adds
     them up in block order.  The total is therefore the same bits for every number of ranks (one rank included):
     block starts are multiples of 2^16 on every shard, so a block's sum is always taken over the same tree
-    nodes.  It equals pgt_dxy_reduce's own total (one query over the whole tree) in neff and nskip, and in the
-    sum to rounding (different association of the same additions).
+    nodes.  It equals pgt_dxy_reduce's own total (since round 5 the sum of the build waves' partial sums in wave
+    order — fixed by the static build grid, i.e. by the size of the input) in neff and nskip exactly, and in the
+    sum to rounding (different association of the same additions; both are held to 1e-13 of the exact sum by
+    tests/test_gpu_parity.py: test_genome_wide_dxy_line_is_pinned_to_the_exact_sum).
 
       load_columns(site_lo, site_hi) -> (pos, p1, p2, n1, n2) device columns of those sites
     Returns on dst (rows [DXY_ROW_DTYPE, one per window], total [DXY_TOTAL_DTYPE scalar]); (None, None) elsewhere.

@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
     std::vector<ColumnCache::Col> cols = {{nullptr, sizeof(uint32_t)}, {nullptr, sizeof(double)}, {nullptr, sizeof(double)}};
     bool on_device = false;
     if (cache.load(n, runs, cols)) {
+        device.plan_host_io(true);  // host columns will be uploaded: stage and warm up beside what is left to do
         tab.pos.borrow(static_cast<uint32_t *>(cols[0].data));
         tab.a.borrow(static_cast<double *>(cols[1].data));
         tab.b.borrow(static_cast<double *>(cols[2].data));
@@ -111,6 +112,7 @@ int main(int argc, char **argv) {
             timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
         }
         if (!on_device && !parsed) {
+            device.plan_host_io(true);  // the host parser's columns will be uploaded: staging ring + first-copy set-up beside the parse
             n = parse_table(text.begin(), text.end(), tab, runs, what, argv[1], 1);
             timer.lap("parse");
             if (cache.enabled()) {

@@ -744,9 +744,15 @@ class DeviceOpener {
             th_.emplace_back([this, k] {
                 ctx_[k] = pgt_open(ids_[k]);
                 if (!ctx_[k]) err_[k] = pgt_last_error(nullptr);  // thread-local in the library: copy it here
-                // the pinned staging ring of the host-buffer entry points (~15 ms of hipHostMalloc): here, beside the parse,
-                // instead of inside the first reduce; a failure is not fatal (the reduce reports it if it needs the ring)
-                else (void)pgt_prepare_host_io(ctx_[k]);
+                // Will this run upload HOST columns (pgt_*_reduce with host pointers: the host parser, the column cache)?  Then
+                // the pinned staging ring and the runtime's one-time set-up of its first copies (50 ... 80 ms in all,
+                // profiles/r06/first_use_probe.txt) are paid HERE, beside the parse, instead of inside the first
+                // reduce.  The main thread says so with plan_host_io() as soon as it knows; runs that parse on the GPU skip it.
+                {
+                    std::unique_lock<std::mutex> lock(m_);
+                    cv_.wait(lock, [this] { return host_io_ >= 0; });
+                }
+                if (host_io_ == 1 && ctx_[k]) (void)pgt_prepare_host_io(ctx_[k]);  // a failure is not fatal: the reduce reports it if it needs the ring
             });
     }
     ~DeviceOpener() {
@@ -755,6 +761,14 @@ class DeviceOpener {
             if (c) pgt_close(c);
     }
     size_t count() const { return ids_.size(); }
+    // the first call decides; get() decides "no" if nobody has said anything by then
+    void plan_host_io(bool wanted) {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            if (host_io_ < 0) host_io_ = wanted ? 1 : 0;
+        }
+        cv_.notify_all();
+    }
     pgt_ctx *get(size_t k = 0) {
         join();
         if (!ctx_[k]) die("libpgtwin: " + err_[k]);
@@ -763,9 +777,13 @@ class DeviceOpener {
 
   private:
     void join() {
+        plan_host_io(false);
         for (auto &t : th_)
             if (t.joinable()) t.join();
     }
+    std::mutex m_;
+    std::condition_variable cv_;
+    int host_io_ = -1;  // -1 undecided, 0 no, 1 yes
     std::vector<int> ids_;
     std::vector<pgt_ctx *> ctx_;
     std::vector<std::string> err_;

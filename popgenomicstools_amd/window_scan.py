@@ -321,6 +321,18 @@ class Context:
             raise PgtError(_lib.PGT_EARG, f"{name}: tensor lives on cuda:{t.device.index}, the context on cuda:{self.device}")
         return t.data_ptr() if t.numel() else None  # an empty shard passes NULL columns (n == 0)
 
+    def _col(self, t, dtype, name):
+        """A COLUMN the build kernels stream: as _dev, plus the alignment the C ABI demands (16 bytes: every column is read
+        by 16-byte loads; ABI 5 extended that to the i32 count columns).  A view that starts at an odd site offset is
+        refused HERE, by name, with the offsets that work — the library's own message cannot name the tensor."""
+        ptr = self._dev(t, dtype, name)
+        if ptr is not None and ptr % 16:
+            import torch
+            per = 16 // torch.empty(0, dtype=dtype).element_size()
+            raise PgtError(_lib.PGT_EARG, f"{name}: column starts {ptr % 16} bytes past a 16-byte boundary; slice columns at site offsets "
+                                          f"that are multiples of {per} for {dtype} (or .clone() the view)")
+        return ptr
+
     @staticmethod
     def _same_len(name, n, *cols):
         """The C ABI takes one n for all columns: a short column would be read out of bounds."""
@@ -446,8 +458,8 @@ class Context:
         self._room("fst_reduce_dev: out", out, n_win * FST_ROW_DTYPE.itemsize)
         self._room("fst_reduce_dev: tree", tree, tb)
         self._check(self._lib.pgt_fst_reduce_dev(
-            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(a, torch.float64, "a"),
-            self._dev(b, torch.float64, "b"), n, self._dev(win, torch.uint8, "win"), n_win,
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._col(a, torch.float64, "a"),
+            self._col(b, torch.float64, "b"), n, self._dev(win, torch.uint8, "win"), n_win,
             self._dev(out, torch.uint8, "out"), out.numel(), self._dev(tree, torch.uint8, "tree"), tree.numel(),
             self._stream(stream)))
         return out, tree
@@ -465,8 +477,8 @@ class Context:
         self._same_len("fst_reduce_pairs_dev", n, pos, *a_list, *b_list)
         self._room("fst_reduce_pairs_dev: out", out, n_pairs * n_win * FST_ROW_DTYPE.itemsize)
         self._room("fst_reduce_pairs_dev: tree", tree, tb)
-        pa = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "a") for t in a_list])
-        pb = (C.c_void_p * n_pairs)(*[self._dev(t, torch.float64, "b") for t in b_list])
+        pa = (C.c_void_p * n_pairs)(*[self._col(t, torch.float64, "a") for t in a_list])
+        pb = (C.c_void_p * n_pairs)(*[self._col(t, torch.float64, "b") for t in b_list])
         self._check(self._lib.pgt_fst_reduce_pairs_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), pa, pb, n_pairs, n,
             self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
@@ -485,7 +497,7 @@ class Context:
         self._room("het_reduce_dev: out", out, n_win * HET_ROW_DTYPE.itemsize)
         self._room("het_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_HET, n))
         self._check(self._lib.pgt_het_reduce_dev(
-            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(g, torch.int8, "g"), n,
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._col(g, torch.int8, "g"), n,
             self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree
@@ -508,8 +520,8 @@ class Context:
         self._room("dxy_reduce_dev: out", out, n_win * DXY_ROW_DTYPE.itemsize)
         self._room("dxy_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_DXY, n))
         self._check(self._lib.pgt_dxy_reduce_dev(
-            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
-            self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._col(p1, torch.float64, "p1"),
+            self._col(p2, torch.float64, "p2"), self._col(n1, torch.int32, "n1"), self._col(n2, torch.int32, "n2"),
             n, int(minind), self._dev(win, torch.uint8, "win") if n_win else None, n_win,
             self._dev(out, torch.uint8, "out") if n_win else None, out.numel(),
             self._dev(tot, torch.uint8, "tot") if tot is not None else None,
@@ -532,9 +544,9 @@ class Context:
         self._same_len("dxy_het_reduce_dev", n, pos, p1, p2, n1, n2, g1, g2)
         self._room("dxy_het_reduce_dev: tree", tree, self.tree_bytes(PGT_STAT_DXY, n) + 2 * self.tree_bytes(PGT_STAT_HET, n))
         self._check(self._lib.pgt_dxy_het_reduce_dev(
-            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(p1, torch.float64, "p1"),
-            self._dev(p2, torch.float64, "p2"), self._dev(n1, torch.int32, "n1"), self._dev(n2, torch.int32, "n2"),
-            self._dev(g1, torch.int8, "g1"), self._dev(g2, torch.int8, "g2"), n, int(minind),
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._col(p1, torch.float64, "p1"),
+            self._col(p2, torch.float64, "p2"), self._col(n1, torch.int32, "n1"), self._col(n2, torch.int32, "n2"),
+            self._col(g1, torch.int8, "g1"), self._col(g2, torch.int8, "g2"), n, int(minind),
             self._dev(win, torch.uint8, "win"), n_win, self._dev(dxy_out, torch.uint8, "dxy_out"), dxy_out.numel(),
             self._dev(tot, torch.uint8, "tot"), self._dev(h1, torch.uint8, "het_out1"),
             self._dev(h2, torch.uint8, "het_out2"), min(h1.numel(), h2.numel()), self._dev(tree, torch.uint8, "tree"),
@@ -557,7 +569,7 @@ class Context:
         self._same_len("fst_af_reduce_dev", n, pos, *freqs)
         self._room("fst_af_reduce_dev: out", out, n_pairs * n_win * FST_ROW_DTYPE.itemsize)
         self._room("fst_af_reduce_dev: tree", tree, tb)
-        pf = (C.c_void_p * n_pops)(*[self._dev(t, torch.float64, "freq") for t in freqs])
+        pf = (C.c_void_p * n_pops)(*[self._col(t, torch.float64, "freq") for t in freqs])
         ns = (C.c_double * n_pops)(*[float(x) for x in nsamp])
         self._check(self._lib.pgt_fst_af_reduce_dev(
             self._ctx, self._dev(pos, torch.int32, "pos"), pf, ns, n_pops, n, self._dev(win, torch.uint8, "win"),
@@ -579,7 +591,7 @@ class Context:
         self._room("extreme_reduce_dev: out", out, n_win * EXT_ROW_DTYPE.itemsize)
         self._room("extreme_reduce_dev: tree", tree, tb)
         self._check(self._lib.pgt_extreme_reduce_dev(
-            self._ctx, self._dev(pos, torch.int32, "pos"), self._dev(score, torch.float64, "score"), n, int(mode),
+            self._ctx, self._dev(pos, torch.int32, "pos"), self._col(score, torch.float64, "score"), n, int(mode),
             float(cutoff), self._dev(win, torch.uint8, "win"), n_win, self._dev(out, torch.uint8, "out"), out.numel(),
             self._dev(tree, torch.uint8, "tree"), tree.numel(), self._stream(stream)))
         return out, tree

@@ -1362,3 +1362,159 @@ def test_reduce_over_a_device_table_equals_reduce_over_the_host_table(pgt, ctx):
         rows_h, tot_h = ctx.dxy_reduce(pos, p1, p2, n1, n2, 5, win)
         assert rows_t.tobytes() == rows_h.tobytes() and tot_t.tobytes() == tot_h.tobytes(), (W, S)
         tab.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: the advisor's edge cases
+# ---------------------------------------------------------------------------------------------
+def test_misaligned_column_views_are_refused_by_name(pgt, ctx):
+    """ABI 5 reads the i32 count columns by 16-byte loads too: a view that starts 2 sites into an allocation (8-byte
+    aligned, fine until ABI 4) is refused by the WRAPPER, naming the tensor and the site offsets that work; the same views
+    at 4 sites are accepted and give the rows of freshly allocated copies, bit for bit.  f64 and i8 columns likewise."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(61)
+    n = 300_016
+    chr_ids, pos = synth.chromosomes(rng, n, 2)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    g = synth.het_column(rng, n).astype(np.int8)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    tp, t1, t2, tn1, tn2, tg = t(pos.view(np.int32)), t(p1), t(p2), t(n1), t(n2), t(g)
+
+    def table(k):  # the window table of the sites from k on
+        return pgt.build_windows_sites(pgt.run_lengths(chr_ids[k:]), 20_000, 5_000)
+
+    for k, name in ((2, "n1"), (2, "n2")):
+        cols = {"n1": tn1[4:], "n2": tn2[4:]}
+        cols[name] = (tn1 if name == "n1" else tn2)[k:k + n - 4]  # 8 bytes past a 16-byte boundary
+        with pytest.raises(_lib.PgtError) as e:
+            ctx.dxy_reduce_dev(tp[4:], t1[4:], t2[4:], cols["n1"], cols["n2"], 5, windows_to_device(table(4), dev))
+        assert name in str(e.value) and "multiples of 4" in str(e.value)
+    with pytest.raises(_lib.PgtError) as e:
+        ctx.fst_reduce_dev(tp[1:], t1[1:], t2[1:], windows_to_device(table(1), dev))
+    assert "a:" in str(e.value) and "multiples of 2" in str(e.value)
+    with pytest.raises(_lib.PgtError) as e:
+        ctx.het_reduce_dev(tp[8:], tg[8:], windows_to_device(table(8), dev))
+    assert "g:" in str(e.value) and "multiples of 16" in str(e.value)
+    # aligned views: 4 sites in for i32 / f64, 16 for i8 — the rows of fresh copies
+    win4, win16 = table(4), table(16)
+    out, tot, _ = ctx.dxy_reduce_dev(tp[4:], t1[4:], t2[4:], tn1[4:], tn2[4:], 5, windows_to_device(win4, dev))
+    ref, rtot, _ = ctx.dxy_reduce_dev(tp[4:].clone(), t1[4:].clone(), t2[4:].clone(), tn1[4:].clone(), tn2[4:].clone(), 5,
+                                      windows_to_device(win4, dev))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(tot, rtot)
+    hout, _ = ctx.het_reduce_dev(tp[16:], tg[16:], windows_to_device(win16, dev))
+    href, _ = ctx.het_reduce_dev(tp[16:].clone(), tg[16:].clone(), windows_to_device(win16, dev))
+    torch.cuda.synchronize()
+    assert torch.equal(hout, href)
+
+
+def test_genome_wide_dxy_line_is_pinned_to_the_exact_sum(pgt, ctx):
+    """The genome-wide dxy line is the sum of the build waves' partial sums in wave order (round 5): its low bits follow the
+    build grid, not only the data.  Pinned here so that a retune of the launch geometry shows as a test to look at, not as a
+    silently different TSV: (1) against the EXACT sum of the per-site values (math.fsum of the host formula, which the device
+    reproduces bit for bit per site) to 1e-13 relative — a wave-order sum of <= 2048 partials of pairwise sums stays well inside;
+    (2) against the block-ordered total of the sharded scan (2^16-site blocks added in order: the same bits for every rank
+    count) to 1e-13; (3) the counts exactly; (4) two calls, same bits (the static grid is a function of the size alone)."""
+    import math
+    import torch
+    from popgenomicstools_amd.distributed import sharded_dxy_scan
+    dev = torch.device("cuda:0")
+    n = 5_000_003
+    g = _genome(99, n, 4)
+    win = pgt.build_windows_sites(g.run_len, 50_000, 10_000)
+
+    def cols(lo, hi):
+        return (g.pos_t(lo, hi, dev),) + tuple(g.dxy_columns_t(lo, hi, dev))
+    c = cols(0, n)
+    minind = 5
+    _, tot, _ = ctx.dxy_reduce_dev(*c, minind, windows_to_device(win, dev))
+    _, tot2, _ = ctx.dxy_reduce_dev(*c, minind, windows_to_device(win, dev))
+    torch.cuda.synchronize()
+    t = rows_from_device(tot, DXY_TOTAL_DTYPE)[0]
+    assert rows_from_device(tot2, DXY_TOTAL_DTYPE).tobytes() == rows_from_device(tot, DXY_TOTAL_DTYPE).tobytes()
+    p1, p2, n1, n2 = (x.cpu().numpy() for x in c[1:])
+    keep = (n1 >= minind) & (n2 >= minind)
+    d = p1 * (1.0 - p2) + p2 * (1.0 - p1)  # dxyWindow.cpp:381, numpy = the host's IEEE arithmetic, no contraction
+    exact = math.fsum(d[keep].tolist())
+    assert int(t["neff"]) == int(keep.sum()) and int(t["nskip"]) == n - int(keep.sum())
+    assert abs(float(t["sum"]) - exact) <= 1e-13 * abs(exact), (float(t["sum"]), exact)
+    _, total = sharded_dxy_scan(win, n, cols, ctx, minind, dev)
+    assert int(total["neff"]) == int(t["neff"]) and int(total["nskip"]) == int(t["nskip"])
+    assert abs(float(total["sum"]) - float(t["sum"])) <= 1e-13 * abs(exact)
+    assert abs(float(total["sum"]) - exact) <= 1e-13 * abs(exact)
+
+
+@pytest.mark.parametrize("n", [8192 * 64, 8192 * 64 + 15, 1024 * 64, 1024 * 64 + 1, 128 * 64, 300_017])
+def test_fast_query_paths_equal_the_general_path_at_their_edges(pgt, ctx, n):
+    """The two-level fast paths of the per-window query (range_partial_two_levels, HetTraits::sum_two_ranges, the het tree
+    built to one level) against the general walk (no hint: every level built, range_partial): windows whose ends sit on and
+    around multiples of 16 / 128 / 1024 / 8192 and within the last 15 sites of the column (the ragged-end fallback), sizes
+    with exactly 64 level-1 or level-2 nodes, empty left / right sides, and a hint that a longer window violates — het, dxy
+    and fst rows byte for byte for max_window in {50000, 65535, 65536} against max_window = 0."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    pos = np.arange(1, n + 1, dtype=np.uint32)
+    a, b = synth.fst_columns(rng, n)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    g = synth.het_column(rng, n).astype(np.int8)
+    edges = set()
+    for m in (16, 128, 1024, 8192):
+        for k in (1, 2, 3, 7, n // m - 1, n // m):
+            for d in (-1, 0, 1):
+                edges.add(k * m + d)
+    edges |= set(range(n - 16, n + 1)) | {0, 1, 15, 17}
+    edges = sorted(e for e in edges if 0 <= e <= n)
+    spans = []
+    for lo in edges:
+        for length in (1, 15, 16, 17, 127, 129, 1023, 1025, 8191, 8193, 49_999, 50_000, 65_535, 65_536, 70_000):
+            if lo + length <= n:
+                spans.append((lo, lo + length))
+    for hi in edges:  # windows that END at an edge
+        for length in (1, 16, 1000, 50_000):
+            if hi - length >= 0:
+                spans.append((hi - length, hi))
+    spans = sorted(set(spans))
+    win = np.zeros(len(spans), dtype=WIN_DTYPE)
+    win["lo"] = [s[0] for s in spans]
+    win["hi"] = [s[1] for s in spans]
+    t = lambda x: torch.from_numpy(x).to(dev)
+    tp, ta, tb, t1, t2, tn1, tn2, tg = t(pos.view(np.int32)), t(a), t(b), t(p1), t(p2), t(n1), t(n2), t(g)
+    wd = windows_to_device(win, dev)
+
+    def rows():
+        f, _ = ctx.fst_reduce_dev(tp, ta, tb, wd)
+        h, _ = ctx.het_reduce_dev(tp, tg, wd)
+        d, tot, _ = ctx.dxy_reduce_dev(tp, t1, t2, tn1, tn2, 3, wd)
+        fused = ctx.dxy_het_reduce_dev(tp, t1, t2, tn1, tn2, tg, tg, 3, wd)
+        torch.cuda.synchronize()
+        return [x.cpu().numpy().tobytes() for x in (f, h, d, fused[0], fused[2], fused[3])], rows_from_device(tot, DXY_TOTAL_DTYPE)[0]
+
+    try:
+        ctx.set_max_window(0)
+        base, btot = rows()
+        assert base[2] == base[3] and base[1] == base[4] == base[5]  # fused == separate
+        # integer truth for the het rows of the general path itself (numpy prefix sums)
+        nm = np.concatenate(([0], np.cumsum(g >= 0)))
+        nh = np.concatenate(([0], np.cumsum(g == 1)))
+        hr = np.frombuffer(base[1], dtype=HET_ROW_DTYPE)
+        assert np.array_equal(hr["nonmissing"], (nm[win["hi"].astype(np.int64)] - nm[win["lo"].astype(np.int64)]).astype(np.uint32))
+        assert np.array_equal(hr["nhet"], (nh[win["hi"].astype(np.int64)] - nh[win["lo"].astype(np.int64)]).astype(np.uint32))
+        for mw in (50_000, 65_535, 65_536):
+            ctx.set_max_window(mw)
+            got, gtot = rows()
+            inside = (win["hi"] - win["lo"]) <= mw  # windows the hint is true for: the same bytes; longer ones: a too-small hint
+            # only changes the order of a float sum (test_max_window_hint_only_changes_speed) — integers exact, floats to 1e-9
+            for k, (name, dt) in enumerate((("fst", FST_ROW_DTYPE), ("het", HET_ROW_DTYPE), ("dxy", DXY_ROW_DTYPE), ("fused dxy", DXY_ROW_DTYPE),
+                                            ("fused het 1", HET_ROW_DTYPE), ("fused het 2", HET_ROW_DTYPE))):
+                gr, br = np.frombuffer(got[k], dtype=dt), np.frombuffer(base[k], dtype=dt)
+                assert gr[inside].tobytes() == br[inside].tobytes(), (name, mw, n)
+                for f in dt.names:
+                    if dt[f].kind == "f":
+                        assert_close(gr[f][~inside], br[f][~inside], f"{name}.{f} beyond the hint {mw}")
+                    else:
+                        assert np.array_equal(gr[f][~inside], br[f][~inside]), (name, f, mw, n)
+            assert int(gtot["neff"]) == int(btot["neff"]) and int(gtot["nskip"]) == int(btot["nskip"])
+    finally:
+        ctx.set_max_window(0)

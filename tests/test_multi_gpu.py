@@ -176,3 +176,60 @@ def test_all_five_hosts_on_two_gpus_print_the_single_gpu_tsv(tmp_path):
     xp.write_text("id\tpos\tgpos\tp1\tihh1\tp2\tihh2\txpehh\tnormxpehh\tcrit\n" +
                   "".join(f"chr{c}_{p}\t{p}\t0.1\t0.3\t1.1\t0.4\t2.2\t0.5\t{s}\t0\n" for c, p, s in zip(chr_ids.tolist(), pos.tolist(), score.tolist())))
     same_on_two([os.path.join(BIN, "xpehhWindow"), str(xp), "2", "-winsize", "30000"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_gpus_pairs_workload_rccl_gather_and_peer_stores():
+    """BASELINE configs[4] on two GPUs as a user would type it: `python bench.py --gpus 2 --workload pairs` — 28 population
+    pairs batched per launch, site ranges sharded, 28 x windows rows per rank delivered by the RCCL gather and by peer stores,
+    each assembled (re-interleaved: table-major over ALL windows) table bitwise the single-GPU call's."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pairs", "--pairs", "28", "--sites", "2e7",
+                        "--chroms", "6", "--steps", "5", "--warmup", "2", "--exchange", "both"], capture_output=True, text=True,
+                       env=dict(_env(), PGT_BENCH_BACKEND="gloo", PGT_BENCH_SHARE_GPU="1") if PRETEND else _env(), timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ok"] is True and line["degraded"] is False
+    assert "28 population pairs" in line["metric"]
+    assert line["config"]["collective_backend"] == ("nccl (RCCL)" if not PRETEND else "gloo (REHEARSAL: PGT_BENCH_BACKEND)"), line["config"]["collective_backend"]
+    assert line["rows_check"].startswith("bitwise equal")
+    assert line["extra"]["exchange_gather"]["rows_check"] == "bitwise equal"
+    assert line["extra"]["exchange_peer"].get("rows_check") == "bitwise equal", line["extra"]["exchange_peer"]
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 16.0 * 28 * line["config"]["sites_resident_per_gpu"][0]
+
+
+@pytest.mark.timeout(900)
+def test_hosts_reduce_in_passes_over_two_gpus(tmp_path):
+    """PGT_DEVICES=0,1 together with PGT_MAX_RESIDENT_SITES (inputs beyond the GPUs' memory: the table is reduced block by
+    block, the blocks dealt to the GPUs, one host thread and context each): fstWindow, hetWindow and dxyWindow print the
+    bytes of the single-GPU single-pass run, for limits that give every GPU several passes and for one that gives the second
+    GPU nothing to do."""
+    import oracle_bind
+    import synth
+    from popgenomicstools_amd import build
+    build.build_lib()
+    build.build_hosts()
+    orc = oracle_bind.load()
+    rng = np.random.default_rng(321)
+    n = 1_200_000
+    chr_ids, pos = synth.chromosomes(rng, n, 4, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    g = synth.het_column(rng, n)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    f, h, m1, m2 = (tmp_path / x for x in ("fst.txt", "het.txt", "p1.mafs", "p2.mafs"))
+    orc.write_fst_text(str(f), chr_ids, pos, a, b)
+    orc.write_het_text(str(h), chr_ids, pos, g)
+    orc.write_maf_text(str(m1), chr_ids, pos, p1, n1)
+    orc.write_maf_text(str(m2), chr_ids, pos, p2, n2)
+    cmds = [[os.path.join(BIN, "fstWindow"), str(f), "50000", "10000"],
+            [os.path.join(BIN, "hetWindow"), str(h), "50000", "10000"],
+            [os.path.join(BIN, "dxyWindow"), "-winsize", "50000", "-stepsize", "10000", "-minind", "5", "-fixedsite", "1", str(m1), str(m2)]]
+    lists = ("0,1", "1,0") if not PRETEND else ("0,0",)
+    for cmd in cmds:
+        one = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert one.returncode == 0 and len(one.stdout.splitlines()) > 50, one.stderr[-500:]
+        for limit in ("150000", "400000", "2000000"):  # 8 passes, 3 passes, one pass (the whole table fits one GPU)
+            for devs in lists:
+                two = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                                     env=dict(os.environ, PGT_DEVICES=devs, PGT_MAX_RESIDENT_SITES=limit))
+                assert (two.returncode, two.stdout) == (0, one.stdout), (cmd[0], limit, devs, two.stderr[-500:])
+                assert two.stderr == one.stderr, (cmd[0], limit, devs)  # dxyWindow: the genome-wide line

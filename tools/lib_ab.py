@@ -57,8 +57,28 @@ def burst(ctx, fn):
     return ctx.last_kernel_ms()[0], e0.elapsed_time(e1) / BURST
 
 
+class _Report:
+    """AB_REPORT=<path>: the markdown also goes to that file — which must NOT exist yet (round 5 lost two A/B records to a
+    later run writing over them; a record that a kernel comment cites must stay what it was)."""
+
+    def __init__(self, path):
+        if os.path.exists(path):
+            sys.exit(f"lib_ab.py: {path} exists already — reports are never overwritten; choose another name")
+        self.fh, self.out = open(path, "x"), sys.stdout
+
+    def write(self, text):
+        self.out.write(text)
+        self.fh.write(text)
+
+    def flush(self):
+        self.out.flush()
+        self.fh.flush()
+
+
 def main():
     global BURST
+    if os.environ.get("AB_REPORT"):
+        sys.stdout = _Report(os.environ["AB_REPORT"])
     old = os.path.abspath(sys.argv[1])
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 10
