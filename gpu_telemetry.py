@@ -139,15 +139,20 @@ class Telemetry:
                 except Exception as e:  # noqa: BLE001
                     out["amdsmi_error"] = f"{type(e).__name__}: {e}"
                 if not light:
-                    for name, fn in (("power_info", "amdsmi_get_power_info"), ("power_cap_info", "amdsmi_get_power_cap_info"),
-                                     ("violation_status", "amdsmi_get_violation_status"), ("perf_level", "amdsmi_get_gpu_perf_level")):
-                        try:
-                            v = getattr(self.smi, fn)(self.handle)
-                            if isinstance(v, dict):
-                                v = {k: x for k, x in v.items() if isinstance(x, (int, float, str, bool)) and x != "N/A"}
-                            out[name] = v if isinstance(v, (dict, int, float, str)) else str(v)
-                        except Exception:  # noqa: BLE001
-                            pass
+                    try:
+                        cap = self.smi.amdsmi_get_power_cap_info(self.handle)
+                        out["power_cap_w"] = round(float(cap.get("power_cap", 0)) * 1e-6, 1)
+                    except Exception:  # noqa: BLE001
+                        pass
+                    try:
+                        out["perf_level"] = str(self.smi.amdsmi_get_gpu_perf_level(self.handle))
+                    except Exception:  # noqa: BLE001
+                        pass
+                    try:  # which limiters are ACTIVE right now (the residency counters above say how long they were)
+                        vio = self.smi.amdsmi_get_violation_status(self.handle)
+                        out["active_limiters"] = sorted(k[7:] for k, x in vio.items() if k.startswith("active_") and x is True)
+                    except Exception:  # noqa: BLE001
+                        pass
             if self.card is not None:
                 s = {}
                 for f in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk"):

@@ -17,7 +17,7 @@
 // build streams 8 B/site/population (64 B/site for 8 populations) instead of the 16 B/site/pair
 // (448 B/site for 28 pairs) of precomputed component columns.
 //
-// Cross-lane cost: V sums per 256-site leaf node would be V six-step butterflies; instead a
+// Cross-lane cost: V sums per leaf node would be V six-step butterflies; instead a
 // REDUCE-SCATTER halves the live values at every exchange step (18+9+5+3+2+1 = 38 exchanges for
 // V = 36), leaving each total in exactly one lane, which stores it and keeps the level-2 running sum.
 #include <hip/hip_runtime.h>
@@ -33,15 +33,16 @@ namespace {
 
 using namespace dev;
 
-// Tree shape of the AF front end: 256-site leaf nodes, 32 of them per level-2 node (8192 sites, as in every other
-// f64 tree), radix 64 above.  Against 128-site leaves (64 per level-2 node, the layout until late in round 2) this
-// halves the node bytes the build writes (3.5 % -> 1.8 % of the bytes read at 8 populations) and the
-// reduce-scatters, and leaves the number and size of the level-2 work items alone: +4.7 / +5.1 / +7.9 points of
-// the HBM peak at 8 / 4 / 2 populations in one session (profiles/r02/af_leaf256.txt).  512-site leaves (16 per
-// level-2 node) gain nothing more on the build within the run-to-run spread and cost the query 25 % (its ragged
-// site ranges double): profiles/r02/af_pieces.txt.  An earlier attempt at 256-site leaves had kept 64 per level-2
-// node: 1-MiB work items, too few of them, no gain.
-constexpr int kAfPieces = 2;                     // 128-site pieces (one 16-byte load per lane and column) per level-1 node
+// Tree shape of the AF front end: 512-site leaf nodes (round 6; 256 until then), 16 of them per level-2 node (8192 sites, as
+// in every other f64 tree), radix 64 above.  What decides the leaf size is the BYTES OF LEVEL-1 NODES THE BUILD WRITES: node
+// stores cost ~6.5 x their share of the kernel's bytes (profiles/r06/af8_issue_stall.md: with the stores removed the
+// 8-population build reads at 86 % of the HBM peak; the arithmetic and the reduce-scatter cost nothing).  128-site leaves
+// (until late in round 2): 3.5 % of the bytes read at 8 populations; 256: 1.8 %, +4.7 / +5.1 / +7.9 points at 8 / 4 / 2
+// populations (profiles/r02/af_leaf256.txt); 512: 0.9 %, +4 points more at 8 populations (76.2 -> 80.5 % with one wave per
+// SIMD) — in round 2 this step had shown nothing, other things bound the kernel then; 1024: 80.5 % at two waves per SIMD, but
+// the query's ragged ends (up to 2 x 1023 sites per window) cost more than the build gains (step 1.164 against 1.105 ms).
+// The query pays for 512 too (ragged ends up to 2 x 511 sites) and therefore requests a side's sites together (af_query_kernel).
+constexpr int kAfPieces = kAfLeafPieces;        // 128-site pieces (one 16-byte load per lane and column) per level-1 node
 constexpr int kAfLeaf = kAfPieces * kLeafF64;    // sites per level-1 node
 constexpr int kAfRadix1 = kRadix / kAfPieces;    // level-1 nodes per level-2 node
 
@@ -165,14 +166,14 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
     return reinterpret_cast<double *>(tv.base + tv.off[level_slot]) + i * V + v;  // node-major: V doubles per node
 }
 
-// ---- BUILD: one wave per level-2 tile (64 pieces of 128 sites = 32 leaf nodes of 256) ---------------
+// ---- BUILD: one wave per level-2 tile (64 pieces of 128 sites = kAfRadix1 leaf nodes of kAfLeaf sites) ---------------
 // BURST > 0: one column at a time (pgt_kernels.hip: fst_build_kernel) — per group of BURST pieces each column's BURST
 // kibibytes are requested and awaited in turn.  Taken for TWO populations only (BURST = 4: 77.7 -> 85.3 % of the HBM peak
 // at 10^9 sites, 74.0 -> 75.6 % at 10^8); with 4 and 8 populations the piece-by-piece form below wins (8 populations: 78.2
 // against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt): there the kernel is bound by
 // its node stores and its arithmetic, and 4 x 8 column registers cost the prefetch of the next piece.
-template <int NP, int BURST = 0>
-__global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
+template <int NP, int BURST>
+__device__ __forceinline__ void af_build_body(const AfCols &cols, uint64_t n, uint64_t n_l2, const AfTree &tv) {
     constexpr int V = Shape<NP>::kVals;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -185,14 +186,14 @@ __global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t 
     const uint32_t lane_bytes = (uint32_t)lane * 16u;  // the lane's 16 bytes of a 1-KiB piece: the only per-lane part of an address
     constexpr uint64_t kTile2 = (uint64_t)kLeafF64 * kRadix;
     // Level-1 nodes are staged in LDS and leave once per level-2 tile as ONE contiguous block (node-major
-    // tree: 32 nodes x V doubles = 9 KiB at 8 populations).  History with 128-site leaves, 8 populations, % of
+    // tree: kAfRadix1 nodes x V doubles = 4.5 KiB at 8 populations and 512-site leaves).  History with 128-site leaves, 8 populations, % of
     // the HBM peak: each leaf total stored straight from the lane that held it (36 scattered 8-byte stores per
     // leaf) 59.6; value-major tree with one 512-byte row per value and tile (36 rows in 36 different arrays)
     // 57-62; node-major blocks 68-75; a timing-only build without level-1 stores 76.9.  As in fst_build_kernel
     // what costs is node writes interleaved with the read stream — the cost goes with their BYTES, not with how
     // they are issued: requesting the next level-2 tile's first leaf BEFORE the block is stored (69.6 vs 71.2 %,
     // profiles/r02/af_pipe.txt), two level-2 tiles staged per flush and / or three leaves prefetched (67.9-69.9
-    // vs 69.7 %, af_stage2.txt) changed nothing; halving the bytes (256-site leaves) did.
+    // vs 69.7 %, af_stage2.txt) changed nothing; halving the bytes (256-site leaves in round 2, 512 in round 6) did.
     extern __shared__ __attribute__((aligned(16))) double af_stage[];
     double *stage = af_stage + (size_t)(threadIdx.x >> 6) * V * kAfRadix1;
 
@@ -258,20 +259,17 @@ __global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t 
 #pragma unroll 1
             for (int i = 0; i < kRadix; i += kAfPieces) {  // one leaf per turn: kAfPieces pieces, two at a time
                 const int j = (i + rot) & (kRadix - 1);  // rot is a multiple of the leaf's pieces: they stay together
-                load_full(pb, j + 1);
-                reduce_piece(std::true_type{}, pa);  // a leaf's first site starts the sums
-                if (i + 2 < kRadix) load_full(pa, (j + 2) & (kRadix - 1));
-                reduce_piece(std::false_type{}, pb);
-                auto next_pair = [&](int h) {
+                auto pair = [&](auto first, int h) {  // pieces j+h (in pa, requested a pair ago) and j+h+1 of the leaf
                     load_full(pb, j + h + 1);
-                    reduce_piece(std::false_type{}, pa);
+                    reduce_piece(first, pa);  // a leaf's first site starts the sums
                     if (i + h + 2 < kRadix) load_full(pa, (j + h + 2) & (kRadix - 1));
                     reduce_piece(std::false_type{}, pb);
                 };
-                if constexpr (kAfPieces == 4) next_pair(2);  // straight-line: rolled, the allocator wants 280 registers for it
+                pair(std::true_type{}, 0);
+                if constexpr (kAfPieces == 4) pair(std::false_type{}, 2);
                 if constexpr (kAfPieces > 4) {
 #pragma unroll 1
-                    for (int h = 2; h < kAfPieces; h += 2) next_pair(h);  // (unrolled, a whole leaf's loads are hoisted: 408 registers at 8 pieces)
+                    for (int h = 2; h < kAfPieces; h += 2) pair(std::false_type{}, h);  // (unrolled, a whole leaf's loads are hoisted: 408 registers at 8 pieces)
                 }
                 rs_steps<V, 0>(vals, lane);  // the leaf is complete: one reduce-scatter per leaf
                 if (my >= 0) stage[(j / kAfPieces) * V + my] = vals[0];  // node j/kAfPieces of the wave's LDS stage: V consecutive doubles (conflict-free)
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t 
                 if (my >= 0) stage[q * V + my] = vals[0];
             }
         }
-        // the level-2 node = the 32 leaf nodes added in LEAF order, whatever order they were produced in (they were added as
+        // the level-2 node = the tile's leaf nodes added in LEAF order, whatever order they were produced in (they were added as
         // produced until round 5: now the walk starts somewhere else in every wave, and the node must not depend on the wave)
         if (my >= 0) {
 #pragma unroll 8
@@ -318,6 +316,28 @@ __global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t 
             }
         }
     }
+}
+
+// Two occupancies of the one body.  The kernel is bound by its node stores and by how many column streams the chip has open
+// at once (profiles/r06/af8_issue_stall.md), not by latency: with 4 or more populations ONE wave per SIMD (4 per CU; the
+// allocator then takes ~280 registers and keeps a whole leaf's loads in flight) beats two — 8 populations, 10^8 sites:
+// 76.2 -> 78.7 % of the HBM peak with 256-site leaves, -> 80.9 % with the 512-site leaves of round 6; two populations (one
+// column at a time, 68 registers) stay at two waves per SIMD.
+template <int NP, int BURST = 0>
+__global__ __launch_bounds__(256, 2) void af_build_kernel(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
+    af_build_body<NP, BURST>(cols, n, n_l2, tv);
+}
+template <int NP, int BURST = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_build_kernel_w1(AfCols cols, uint64_t n, uint64_t n_l2, AfTree tv) {
+    af_build_body<NP, BURST>(cols, n, n_l2, tv);
+}
+// from how many populations on the one-wave-per-SIMD build is taken (PGT_AF_ONE_WAVE_FROM: a measuring knob; 9 = never)
+inline int af_one_wave_from() {
+    static const int v = [] {
+        const char *e = std::getenv("PGT_AF_ONE_WAVE_FROM");
+        return e ? std::atoi(e) : 4;
+    }();
+    return v;
 }
 
 // ---- upper levels: parent = Σ of 64 children, per value (blockIdx.y) -----------------------------
@@ -454,8 +474,11 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         const uint64_t rounds = (tl.count[1] + max_waves - 1) / max_waves;
         const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
         uint64_t blocks = (waves + 3) / 4;
-        constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x 32 nodes x V doubles
-        hipLaunchKernelGGL((af_build_kernel<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x kAfRadix1 nodes x V doubles
+        if (NP >= af_one_wave_from())
+            hipLaunchKernelGGL((af_build_kernel_w1<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
+        else
+            hipLaunchKernelGGL((af_build_kernel<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         if (int rc = hip_fail(hipGetLastError(), "af_build_kernel", err)) return rc;
         for (int k = 2; k < tv.n_levels; ++k) {
             uint64_t b = (tl.count[k] + 3) / 4;
@@ -480,8 +503,9 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
 namespace {
 template <int NP>
 void af_allow_lds() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP, (NP == 2 ? 4 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double)));
+    const int bytes = (int)((size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel_w1<NP, (NP == 2 ? 4 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(af_build_kernel<NP, (NP == 2 ? 4 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 }  // namespace
 

@@ -93,20 +93,21 @@ inline int useful_levels(const TreeLayout &t, int stat, uint64_t max_window) {
 }
 
 // ---- allele-frequency front end (pgt_af_kernels.hip): nodes of V scalar sums, node-major ------
-// A node is V consecutive doubles (V = NP + NP(NP-1)/2), the nodes of a level are contiguous: the 32
-// level-1 nodes (256 sites each) a build wave finishes together are ONE contiguous block of 256*V bytes (9 KiB
+// A node is V consecutive doubles (V = NP + NP(NP-1)/2), the nodes of a level are contiguous: the 16
+// level-1 nodes (512 sites each) a build wave finishes together are ONE contiguous block of 128*V bytes (4.5 KiB
 // at 8 populations), and a query lane reads a node as one contiguous run.  Levels 2 and up are those of the
 // f64 layout (8192 sites, x64 per level).
 constexpr int kAfMaxPops = 8;
+constexpr int kAfLeafPieces = 4;  // 128-site pieces per level-1 node of the AF tree (pgt_af_kernels.hip: kAfPieces)
 struct AfTree {
     char *base;
     size_t off[kMaxLevels];  // byte offset of level slot k
     int n_levels;
     int n_vals;              // V: doubles per node
 };
-// the AF tree's level 1 holds 32 nodes of 256 sites per level-2 node (pgt_af_kernels.hip), half of the f64 layout's count
+// the AF tree's level 1 holds 64 / kAfLeafPieces nodes per level-2 node (pgt_af_kernels.hip), a fraction of the f64 layout's count
 inline size_t af_level_bytes(const TreeLayout &t, int k, int n_vals) {
-    const uint64_t nodes = k == 0 ? t.count[0] / 2 : t.count[k];
+    const uint64_t nodes = k == 0 ? t.count[0] / kAfLeafPieces : t.count[k];
     return ((nodes * (size_t)n_vals * 8 + 255) / 256) * 256;
 }
 inline size_t af_tree_bytes(const TreeLayout &t, int n_vals) {

@@ -763,6 +763,7 @@ class DeviceOpener {
     size_t count() const { return ids_.size(); }
     // the first call decides; get() decides "no" if nobody has said anything by then
     void plan_host_io(bool wanted) {
+        if (const char *e = std::getenv("PGT_PREPARE_HOST_IO"); e && std::atoi(e) == 0) wanted = false;  // A/B knob: set-up inside the first reduce, as until round 5
         {
             std::lock_guard<std::mutex> lock(m_);
             if (host_io_ < 0) host_io_ = wanted ? 1 : 0;
