@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void af_up_kernel(AfTree tv, int child_slot, u
 
 // ---- QUERY: one wave per window, all pairs at once ---------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32_t *__restrict__ pos, AfTree tv,
+__global__ __launch_bounds__(256, 2) void af_query_kernel(AfCols cols, const uint32_t *__restrict__ pos, AfTree tv,
                                                        const pgt_win *__restrict__ win, uint64_t n_win,
                                                        pgt_fst_row *__restrict__ out, uint64_t n_sites) {
     constexpr int V = Shape<NP>::kVals;
@@ -377,10 +377,10 @@ __global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32
         // A window's answer is a chain of dependent memory round trips (its table entry, ragged sites left and right, ragged
         // nodes left and right of every level, the top level, its coordinates), ~1.5 us each under load: until round 6 there
         // were up to 13 of them — every 64 ragged sites were a trip of their own.  Now a side's ragged sites are REQUESTED TOGETHER,
-        // before the first addition (up to kAfLeaf / 64 strides in flight at once), which leaves 7.  (Both ragged sides of a node
-        // level in flight together would save one more trip per level and cost 72 more registers: 320, one wave per SIMD.)
-        // Each lane still adds its items in the order it did (left before right, strides ascending): rows bit for bit those of
-        // the stride-by-stride form.
+        // before the first addition (up to 8 strides of 64 sites in flight at once), and the two ragged sides of level 1 (fewer
+        // than 16 nodes each) go to the two halves of the wave in one trip: 6 are left.  A window's sum depends on the window
+        // alone (lane j always adds the same items in the same order), not on which other windows are asked for or on how many
+        // GPUs share the table.
         constexpr int kStrides = kAfLeaf / kWave < 8 ? kAfLeaf / kWave : 8;  // a ragged side holds fewer than kAfLeaf sites; 8 strides = 128 registers at 8 populations
         auto sum_sites = [&](uint64_t from, uint64_t to) {
             for (uint64_t at = from; at < to; at += (uint64_t)kStrides * kWave) {
@@ -412,7 +412,22 @@ __global__ __launch_bounds__(256) void af_query_kernel(AfCols cols, const uint32
                 break;
             }
             if (k == 0) { sum_sites(clo, ulo * r); sum_sites(uhi * r, chi); }
-            else { sum_nodes(k, clo, ulo * r); sum_nodes(k, uhi * r, chi); }
+            else {
+                // both ragged sides of a node level in ONE trip when each holds at most 32 nodes (always on level 1: fewer than
+                // kAfRadix1 = 16): lanes 0-31 take the left side's nodes, lanes 32-63 the right side's
+                const uint64_t nl = ulo * r - clo, nr = chi - uhi * r;
+                if (nl <= 32 && nr <= 32) {
+                    const uint64_t q = (uint64_t)(lane & 31);
+                    if (lane < 32 ? q < nl : q < nr) {
+                        const uint64_t i = lane < 32 ? clo + q : uhi * r + q;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[v] += *af_node<V>(tv, k - 1, v, i);
+                    }
+                } else {
+                    sum_nodes(k, clo, ulo * r);
+                    sum_nodes(k, uhi * r, chi);
+                }
+            }
             clo = ulo;
             chi = uhi;
         }
