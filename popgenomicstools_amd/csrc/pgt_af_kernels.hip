@@ -377,23 +377,41 @@ __global__ __launch_bounds__(256, 2) void af_query_kernel(AfCols cols, const uin
         // A window's answer is a chain of dependent memory round trips (its table entry, ragged sites left and right, ragged
         // nodes left and right of every level, the top level, its coordinates), ~1.5 us each under load: until round 6 there
         // were up to 13 of them — every 64 ragged sites were a trip of their own.  Now a side's ragged sites are REQUESTED TOGETHER,
-        // before the first addition (up to 8 strides of 64 sites in flight at once), and the two ragged sides of level 1 (fewer
-        // than 16 nodes each) go to the two halves of the wave in one trip: 6 are left.  A window's sum depends on the window
+        // before the first addition (256 sites in flight at once), and the two ragged sides of level 1 (fewer
+        // than 16 nodes each) go to the two halves of the wave in one trip: 8 are left (two per ragged side of up to 511 sites).  A window's sum depends on the window
         // alone (lane j always adds the same items in the same order), not on which other windows are asked for or on how many
         // GPUs share the table.
-        constexpr int kStrides = kAfLeaf / kWave < 8 ? kAfLeaf / kWave : 8;  // a ragged side holds fewer than kAfLeaf sites; 8 strides = 128 registers at 8 populations
+        // ... by 16-byte loads: a lane takes the PAIR of sites 2j, 2j+1 of a 128-site stride (the columns are 16-byte aligned, so an
+        // even site index is a 16-byte boundary), two strides (256 sites) in flight at once; the pair's halves outside [from, to)
+        // are skipped, the column's very last site (odd n) is read alone, by lane 0.  Measured at 8 populations, 10^8 sites,
+        // 512-site leaves (profiles/r06/round6_f_ab_af_query.md, whole step): 8-byte loads with 8 strides of 64 sites in flight
+        // 1.113 ms, this form 1.106, four strides of 128 in flight (256 registers and spills) 1.131.
+        constexpr int kStrides = 2;
         auto sum_sites = [&](uint64_t from, uint64_t to) {
-            for (uint64_t at = from; at < to; at += (uint64_t)kStrides * kWave) {
-                double f[kStrides][NP];
+            for (uint64_t at = from & ~(uint64_t)1; at < to; at += (uint64_t)kStrides * kLeafF64) {
+                double2 f[kStrides][NP];
 #pragma unroll
                 for (int t = 0; t < kStrides; ++t) {
-                    const uint64_t i = at + (uint64_t)t * kWave + lane;
+                    const uint64_t i = at + (uint64_t)t * kLeafF64 + 2 * (uint64_t)lane;
+                    const bool in = i < to && i + 1 < n_sites;  // the pair lies inside the column
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) f[t][k] = i < to ? cols.f[k][i] : 0.0;
+                    for (int k = 0; k < NP; ++k) f[t][k] = in ? *reinterpret_cast<const double2 *>(cols.f[k] + i) : double2{0.0, 0.0};
                 }
 #pragma unroll
-                for (int t = 0; t < kStrides; ++t)
-                    if (at + (uint64_t)t * kWave + lane < to) af_accumulate<NP>(acc, f[t]);
+                for (int t = 0; t < kStrides; ++t) {
+                    const uint64_t i = at + (uint64_t)t * kLeafF64 + 2 * (uint64_t)lane;
+                    double fx[NP], fy[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { fx[k] = f[t][k].x; fy[k] = f[t][k].y; }
+                    if (i >= from && i < to && i + 1 < n_sites) af_accumulate<NP>(acc, fx);
+                    if (i + 1 >= from && i + 1 < to) af_accumulate<NP>(acc, fy);
+                }
+            }
+            if ((n_sites & 1) && to == n_sites && from < n_sites && lane == 0) {  // the column's last site when it has no partner
+                double fl[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) fl[k] = cols.f[k][n_sites - 1];
+                af_accumulate<NP>(acc, fl);
             }
         };
         auto sum_nodes = [&](int level, uint64_t from, uint64_t to) {

@@ -1518,3 +1518,53 @@ def test_fast_query_paths_equal_the_general_path_at_their_edges(pgt, ctx, n):
             assert int(gtot["neff"]) == int(btot["neff"]) and int(gtot["nskip"]) == int(btot["nskip"])
     finally:
         ctx.set_max_window(0)
+
+
+def test_host_buffer_calls_through_the_staging_ring_equal_the_device_calls(pgt, ctx, monkeypatch):
+    """The host-buffer entry points INTEGRATION.md binds (pgt_fst_reduce / pgt_het_reduce / pgt_dxy_reduce / pgt_extreme_reduce)
+    with inputs large enough to take the pinned staging ring (>= 32 MiB of columns; several 16-MiB pieces per column, ragged last
+    pieces): rows bit for bit those of the device-resident calls and of the plain-hipMemcpy path (PGT_UPLOAD=plain), with and
+    without pgt_prepare_host_io, and again after calls of other sizes have grown and reused the context's workspace."""
+    import torch
+    from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS
+    import popgenomicstools_amd as pg
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(71)
+    n = 8_000_037  # hetWindow: 40 MB of columns, the smallest of the four, still above the ring threshold of 32 MiB
+    chr_ids, pos = synth.chromosomes(rng, n, 3, equal=False)
+    a, b = synth.fst_columns(rng, n)
+    p1, p2, n1, n2 = synth.dxy_columns(rng, n)
+    g = synth.het_column(rng, n).astype(np.int8)
+    win = pgt.build_windows_sites(pgt.run_lengths(chr_ids), 50_000, 10_000)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    wd = windows_to_device(win, dev)
+    tp = t(pos.view(np.int32))
+    ref_f = rows_from_device(ctx.fst_reduce_dev(tp, t(a), t(b), wd)[0], FST_ROW_DTYPE).tobytes()
+    ref_h = rows_from_device(ctx.het_reduce_dev(tp, t(g), wd)[0], HET_ROW_DTYPE).tobytes()
+    d_out, d_tot, _ = ctx.dxy_reduce_dev(tp, t(p1), t(p2), t(n1), t(n2), 5, wd)
+    ref_d, ref_t = rows_from_device(d_out, DXY_ROW_DTYPE).tobytes(), rows_from_device(d_tot, DXY_TOTAL_DTYPE).tobytes()
+    ewin = pgt.build_windows_extreme(pos, pgt.run_lengths(chr_ids), None, 200_000)
+    ref_e = rows_from_device(ctx.extreme_reduce_dev(tp, t(a), PGT_EXT_IHS, 0.9, windows_to_device(ewin, dev))[0], EXT_ROW_DTYPE).tobytes()
+    torch.cuda.synchronize()
+
+    def host_rows(c):
+        d, tot = c.dxy_reduce(pos, p1, p2, n1, n2, 5, win)
+        return (c.fst_reduce(pos, a, b, win).tobytes(), c.het_reduce(pos, g, win).tobytes(), d.tobytes(), np.array([tot]).tobytes(),
+                c.extreme_reduce(pos, a, PGT_EXT_IHS, 0.9, ewin).tobytes())
+
+    want = (ref_f, ref_h, ref_d, ref_t, ref_e)
+    assert host_rows(ctx) == want                      # ring, allocated inside the first call
+    small = pgt.build_windows_sites(np.array([1000], dtype=np.uint64), 100, 50)
+    assert ctx.fst_reduce(pos[:1000], a[:1000], b[:1000], small).size == small.size   # a small call in between (plain path, workspace reused)
+    assert host_rows(ctx) == want                      # again: every buffer of the workspace already large enough
+    with pg.Context(0) as c2:                          # a fresh context, prepared up front
+        c2.prepare_host_io()
+        c2.prepare_host_io()                           # idempotent
+        assert host_rows(c2) == want
+    monkeypatch.setenv("PGT_UPLOAD", "plain")          # round 5's path: hipMemcpy from the caller's pageable columns
+    assert host_rows(ctx) == want
+    monkeypatch.setenv("PGT_UPLOAD", "ring")
+    monkeypatch.setenv("PGT_UPLOAD_WORKERS", "5")      # read when a ring is created: a new context with an odd geometry
+    monkeypatch.setenv("PGT_UPLOAD_CHUNK_MIB", "3")
+    with pg.Context(0) as c3:
+        assert host_rows(c3) == want

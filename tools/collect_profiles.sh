@@ -10,9 +10,9 @@
 #   pmc_counters_all_1e8/1e9.csv, pmc_traffic_all_kernels_1e8/1e9.md   per build kernel: FETCH_SIZE / WRITE_SIZE / SQ / TCC counters;
 #                                HBM traffic against the algorithmic bytes and the wave-cycle split (tools/trim_rocprof.py traffic)
 #   bench_2rank_rehearsal.log    plain `python bench.py --gpus 2` (self-launching) with two ranks sharing the one GPU
-# usage: bash tools/collect_profiles.sh r05
+# usage: bash tools/collect_profiles.sh r06
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -117,7 +117,7 @@ def timeline(f):
 
 
 ALG_BYTES_PER_SITE = {"fst_build_kernel": 16, "dxy_build_kernel": 24, "het_build_kernel_w4": 1, "het_build_kernel": 1, "dxy_het_build_kernel": 26,
-                      "af_build_kernel<8": 64, "af_build_kernel<2": 16, "ext_build_kernel": 8}
+                      "af_build_kernel<8": 64, "af_build_kernel_w1<8": 64, "af_build_kernel<2": 16, "ext_build_kernel": 8}
 
 
 def traffic(trimmed, sites):
