@@ -938,12 +938,16 @@ def main():
                                  group=group)
             except PgtError as e:  # peer: the buffer cannot be mapped by every rank (decided collectively)
                 return {"mode": mode, "available": False, "why": str(e)}
-            if tel and "timed_region" not in telemetry:  # a sampler thread beside the headline's timed region (prewarm included)
+            if tel and world == 1 and "timed_region" not in telemetry:  # a sampler thread beside the headline's timed region (prewarm included)
                 telemetry["before_timed"] = tel.snapshot()
                 with tel.sampling(period_s=0.05) as smp:
                     dt_ = timed_region(ex)
                 telemetry["timed_region"] = smp.summary()
                 telemetry["after_timed"] = tel.snapshot(light=True)
+            elif tel and "before_timed" not in telemetry:  # N > 1: a reading before and after, no thread beside rank 0's launch loop
+                telemetry["before_timed"] = tel.snapshot()
+                dt_ = timed_region(ex)
+                telemetry["after_timed"] = tel.snapshot()
             else:
                 dt_ = timed_region(ex)
             table_ = ex.finish()  # rank 0: the assembled table of the last step (uint8 numpy)
