@@ -138,3 +138,68 @@ def test_rows_check_against_the_reference_tsv(tmp_path):
         near = table.copy()
         near["fst"] *= 1 + 5e-10
         assert bench.check_rows_against_tsv(tsv, near, win, n_sample, "test")["equal"] is True
+
+
+def test_rows_check_compares_fst_and_het_rows_with_a_reference_tsv(tmp_path):
+    """bench.check_rows_against_tsv (the live parity checks of the headline run and, round 6, of configs[2]): rows of the windows
+    that end inside the sample against the reference's TSV — coordinates, midpoint, count, label exact, the statistic as printed
+    (`%g`) or within 1e-9 on a rounding boundary; a wrong count, a wrong value and a short TSV are reported, not passed."""
+    import numpy as np
+    from popgenomicstools_amd._lib import FST_ROW_DTYPE, HET_ROW_DTYPE, WIN_DTYPE
+    win = np.zeros(4, dtype=WIN_DTYPE)
+    win["lo"], win["hi"], win["label_run"] = [0, 10, 20, 30], [20, 30, 40, 60], [0, 0, 1, 1]
+    rows = np.zeros(4, dtype=FST_ROW_DTYPE)
+    rows["start"], rows["end"], rows["mid"], rows["n"] = [1, 11, 21, 31], [20, 30, 40, 60], [10, 20, 30, 45], [20, 20, 20, 30]
+    rows["fst"] = [0.25, -4e-05, 1.25e6, 0.5]
+    tsv = tmp_path / "ref.tsv"
+    lines = ["chr1\t1\t20\t10\t0.25\t20", "chr1\t11\t30\t20\t-4e-05\t20", "chr2\t21\t40\t30\t1.25e+06\t20", "chr2\t99\t99\t99\t9\t9"]
+    tsv.write_text("\n".join(lines) + "\n")
+    res = bench.check_rows_against_tsv(str(tsv), rows.view(np.uint8), win, 40, "a reference")  # windows 0..2 end inside 40 sites
+    assert res["equal"] is True and res["windows"] == 3 and res["reference_rows"] == 4 and res["fst_on_a_rounding_boundary"] == 0
+    bad = rows.copy()
+    bad["n"][1] = 19
+    res = bench.check_rows_against_tsv(str(tsv), bad.view(np.uint8), win, 40, "a reference")
+    assert res["equal"] is False and "row 1" in res["mismatch"]
+    bad = rows.copy()
+    bad["fst"][2] = 1.26e6
+    assert bench.check_rows_against_tsv(str(tsv), bad.view(np.uint8), win, 40, "a reference")["equal"] is False
+    near = rows.copy()
+    near["fst"][0] = 0.25 * (1 + 3e-10)  # prints 0.25 too
+    assert bench.check_rows_against_tsv(str(tsv), near.view(np.uint8), win, 40, "a reference")["equal"] is True
+    tsv.write_text("\n".join(lines[:2]) + "\n")
+    res = bench.check_rows_against_tsv(str(tsv), rows.view(np.uint8), win, 40, "a reference")
+    assert res["equal"] is False and "2 rows" in res["mismatch"]
+    # het rows: the value is h, the count column is `nonmissing` (hetWindow.cpp:87)
+    h = np.zeros(4, dtype=HET_ROW_DTYPE)
+    h["start"], h["end"], h["mid"], h["nonmissing"], h["nhet"] = rows["start"], rows["end"], rows["mid"], [18, 20, 0, 5], [9, 5, 0, 1]
+    h["h"] = [0.5, 0.25, 0.0, 0.2]
+    tsv.write_text("chr1\t1\t20\t10\t0.5\t18\nchr1\t11\t30\t20\t0.25\t20\nchr2\t21\t40\t30\t0\t0\n")
+    res = bench.check_rows_against_tsv(str(tsv), h.view(np.uint8), win, 40, "a reference", row_dtype=HET_ROW_DTYPE, value="h", count="nonmissing")
+    assert res["equal"] is True and res["windows"] == 3 and "h_on_a_rounding_boundary" in res
+
+
+def test_telemetry_reader_degrades_to_nothing_and_summarises_samples():
+    """gpu_telemetry: without a driver (this container) every reader is absent and nothing raises; the sampler's summary gives
+    min / median / max per field, per-unit lists as min / max over the units, and the GROWTH of the limiter residency counters."""
+    import gpu_telemetry as g
+    t = g.Telemetry("0000:00:00.0")
+    d = t.describe()
+    assert d["source"] in (["none"], ["sysfs"]) or "amdsmi" in d["source"]
+    assert isinstance(t.snapshot(), dict) and "t" in t.snapshot()
+    assert g._current_dpm("0: 500Mhz\n1: 2208Mhz *\n2: 2400Mhz") == 2208 and g._current_dpm("S: 95Mhz *\n0: 500Mhz") == 95
+    assert g._current_dpm("") is None and g._current_dpm("0: 2000Mhz") is None
+    assert g._num(0xFFFF) is None and g._num("N/A") is None and g._num(47) == 47
+    s = g._Sampler(t, 1.0)
+    s.samples = [{"t": 10.0, "current_socket_power": 1200, "current_gfxclks": [2300, 2350], "ppt_residency_acc": 100, "accumulation_counter": 1000,
+                  "sysfs": {"sclk_mhz": 2340}},
+                 {"t": 10.5, "current_socket_power": 1350, "current_gfxclks": [2310, 2390], "ppt_residency_acc": 160, "accumulation_counter": 1500,
+                  "sysfs": {"sclk_mhz": 2356}},
+                 {"t": 11.0, "current_socket_power": 1300, "current_gfxclks": [2320, 2360], "ppt_residency_acc": 400, "accumulation_counter": 2000,
+                  "sysfs": {"sclk_mhz": 2350}}]
+    out = s.summary()
+    assert out["samples"] == 3 and out["seconds"] == 1.0
+    assert out["current_socket_power"] == {"min": 1200, "median": 1300, "max": 1350, "n": 3}
+    assert out["current_gfxclks_min_over_units"]["min"] == 2300 and out["current_gfxclks_max_over_units"]["max"] == 2390
+    assert out["sysfs_sclk_mhz"]["median"] == 2350
+    assert out["residency_growth"] == {"ppt_residency_acc": 300, "accumulation_counter": 1000}
+    assert g._Sampler(t, 1.0).summary() == {"samples": 0}
