@@ -48,11 +48,13 @@ def main():
             "uclk": med(su, "current_uclk"), "fclk": med(su, "sysfs_fclk_mhz"),
             "other_thr": sum((g(su, k) or 0) for k in ("prochot_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc")),
             "start_power": t.get("at_start", {}).get("current_socket_power"), "start_hbm_c": t.get("at_start", {}).get("temperature_mem"),
-            "pci": t.get("reader", {}).get("pci")})
+            "pci": t.get("reader", {}).get("pci"),
+            "serial": t.get("reader", {}).get("identity", {}).get("asic", {}).get("asic_serial"),
+            "vbios": t.get("reader", {}).get("identity", {}).get("vbios", {}).get("version")})
     if not rows:
         sys.exit("no run succeeded")
     print(f"{len(rows)} processes of `python bench.py --no-cpu --no-exchange-overhead {' '.join(extra_args)}` back to back on one box "
-          f"(GPU {rows[0]['pci']}); t_ = during the headline's timed region (0.5 s), s_ = during the sustained leg (2.5 s)\n")
+          f"(GPU at PCI {rows[0]['pci']}, ASIC serial {rows[0]['serial']}, VBIOS {rows[0]['vbios']}); t_ = during the headline's timed region (0.5 s), s_ = during the sustained leg (2.5 s)\n")
     cols = ["run", "frac", "kernel_ms", "ms_per_step", "sust_GBs", "fst1e8", "af8", "t_sclk", "t_sclk_max", "t_power", "t_ppt", "t_acc", "t_hbm_c",
             "s_sclk", "s_sclk_max", "s_power", "s_ppt", "s_acc", "s_hbm_c", "s_hot_c", "uclk", "fclk", "other_thr", "start_power", "start_hbm_c"]
     print("| " + " | ".join(cols) + " |")
