@@ -93,10 +93,12 @@ void pgt_close(pgt_ctx *ctx);
 const char *pgt_last_error(const pgt_ctx *ctx);
 int pgt_abi_version(void);
 /* Optional: allocate the pinned staging ring of the host-buffer entry points (pgt_*_reduce with host columns) now
- * (~15 ms of hipHostMalloc + the runtime's one-time 30 … 60 ms set-up of the first copies of a process) instead of inside the first such call — the retained hosts call it on the thread that opens
- * the device, beside the text parse.  Replaces nothing in the reference (its calcWindow reads the caller's buffer in place,
- * fstWindow.cpp:76-83); it exists because the columns have to cross PCIe here. */
-int pgt_prepare_host_io(pgt_ctx *ctx);
+ * (~15 ms of hipHostMalloc + the runtime's one-time 30 … 60 ms set-up of the first copies of a process) instead of inside the
+ * first such call — the retained hosts call it on the thread that opens the device, beside the text parse.
+ * expected_column_bytes: what the caller expects to upload per call (0 = unknown); below 32 MiB uploads do not take the ring
+ * and it is not allocated (only the set-up is paid).  Replaces nothing in the reference (its calcWindow reads the caller's
+ * buffer in place, fstWindow.cpp:76-83); it exists because the columns have to cross PCIe here. */
+int pgt_prepare_host_io(pgt_ctx *ctx, uint64_t expected_column_bytes);
 
 /* ---- window tables (host, O(#windows + #runs), no device needed) ------------------------ */
 /* Site-count windows of fstWindow / hetWindow / dxyWindow -fixedsite 1: the emission rules of

@@ -172,7 +172,7 @@ def load() -> C.CDLL:
     lib.pgt_het_reduce_tab.argtypes = [vp, vp, vp, u64, i32, vp, vp, sz]
     lib.pgt_dxy_reduce_tab.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, vp]
     if "pgt_prepare_host_io" in SYMBOLS:  # (tools/lib_ab.py drops it from the list to load a round-5 library beside the tree's)
-        lib.pgt_prepare_host_io.argtypes = [vp]
+        lib.pgt_prepare_host_io.argtypes = [vp, u64]
     _lib = lib
     return lib
 

@@ -381,19 +381,28 @@ void pgt_close(pgt_ctx *ctx) {
     delete ctx;
 }
 
-int pgt_prepare_host_io(pgt_ctx *ctx) {
+int pgt_prepare_host_io(pgt_ctx *ctx, uint64_t expected_column_bytes) {
     PGT_USE_DEVICE(ctx);
-    if (int rc = ring_prepare(ctx)) return rc;
+    // the ring only when uploads will take it (0 = unknown: yes); 15 ms of hipHostMalloc a small input need not wait for
+    const bool ring = expected_column_bytes == 0 || expected_column_bytes >= 4 * HostIo::kChunk;
+    if (ring)
+        if (int rc = ring_prepare(ctx)) return rc;
     // The FIRST copy of a process in each direction and flavour pays for the runtime's own set-up (its DMA queues and staging
-    // buffers: ~85 ms for the first host-to-device copy whatever its size, ~5 ms for the first small pageable one;
-    // tools/probes/host_api_probe.py) — pay it here, beside the caller's parse, with 64 KiB instead of inside the first reduce.
+    // buffers: 20-30 ms for the first GPU operation of any kind, 8-9 ms more for the first host-to-device DMA, ~5 ms for the first
+    // small pageable copy; tools/probes/first_use_probe.cpp, host_api_probe.py) — pay it here, beside the caller's parse, with
+    // 64 KiB instead of inside the first reduce.
     HostIo &io = ctx->io;
     void *scratch = nullptr;
     if (int rc = workspace(ctx, HostIo::kWin, 65536, &scratch)) return rc;
     std::vector<char> pageable(65536, 0);
-    if (int rc = hip_check(ctx, hipMemcpyAsync(scratch, io.pin[0], 65536, hipMemcpyHostToDevice, io.copy_stream), "host io warm-up")) return rc;
-    if (int rc = hip_check(ctx, hipStreamSynchronize(io.copy_stream), "host io warm-up")) return rc;
-    if (int rc = hip_check(ctx, hipMemcpy(scratch, pageable.data(), pageable.size(), hipMemcpyHostToDevice), "host io warm-up")) return rc;
+    void *pinned = ring ? static_cast<void *>(io.pin[0]) : nullptr;
+    if (!pinned)
+        if (int rc = hip_check(ctx, hipHostMalloc(&pinned, 65536, hipHostMallocDefault), "host io warm-up: hipHostMalloc")) return rc;
+    int rc = hip_check(ctx, hipMemcpyAsync(scratch, pinned, 65536, hipMemcpyHostToDevice, io.copy_stream), "host io warm-up");
+    if (!rc) rc = hip_check(ctx, hipStreamSynchronize(io.copy_stream), "host io warm-up");
+    if (!ring) (void)hipHostFree(pinned);
+    if (rc) return rc;
+    if (int rc2 = hip_check(ctx, hipMemcpy(scratch, pageable.data(), pageable.size(), hipMemcpyHostToDevice), "host io warm-up")) return rc2;
     return hip_check(ctx, hipMemcpy(pageable.data(), scratch, pageable.size(), hipMemcpyDeviceToHost), "host io warm-up");
 }
 

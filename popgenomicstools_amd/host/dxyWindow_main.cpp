@@ -520,7 +520,7 @@ int main(int argc, char **argv) {
         }
     }
     if (!parsed) {  // the two files are independent: parse them side by side on the host
-        device.plan_host_io(true);  // their columns will be uploaded: staging ring + first-copy set-up beside the parse
+        device.plan_host_io(true, open1 && open2 ? (uint64_t)t1.size() + t2.size() : 0);  // their columns will be uploaded: staging ring (inputs from 32 MiB) + first-copy set-up beside the parse
         std::string e1, e2;
         std::thread th([&] { read_maf(argv[argc - 2], "Pop1", m1, c1, e1, open1 ? &t1 : nullptr); });
         read_maf(argv[argc - 1], "Pop2", m2, c2, e2, open2 ? &t2 : nullptr);

@@ -125,7 +125,7 @@ inline int run_extreme(const char *path, bool skip_header, int score_field, uint
         }
     }
     if (!on_device) {
-        device.plan_host_io(true);  // the host parser's columns will be uploaded: staging ring + first-copy set-up beside the parse
+        device.plan_host_io(true, (uint64_t)(text.end() - b));  // the host parser's columns will be uploaded: staging ring (inputs from 32 MiB) + first-copy set-up beside the parse
         runs = Runs{};
         n = parse_table(b, text.end(), tab, runs, what, path, first_line);
         timer.lap("parse");

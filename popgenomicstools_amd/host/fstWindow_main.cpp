@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
             timer.lap(on_device ? "gpu parse" : "gpu parse (refused)");
         }
         if (!on_device && !parsed) {
-            device.plan_host_io(true);  // the host parser's columns will be uploaded: staging ring + first-copy set-up beside the parse
+            device.plan_host_io(true, text.size());  // the host parser's columns will be uploaded: staging ring (inputs from 32 MiB) + first-copy set-up beside the parse
             n = parse_table(text.begin(), text.end(), tab, runs, what, argv[1], 1);
             timer.lap("parse");
             if (cache.enabled()) {

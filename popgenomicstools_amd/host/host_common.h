@@ -752,7 +752,7 @@ class DeviceOpener {
                     std::unique_lock<std::mutex> lock(m_);
                     cv_.wait(lock, [this] { return host_io_ >= 0; });
                 }
-                if (host_io_ == 1 && ctx_[k]) (void)pgt_prepare_host_io(ctx_[k]);  // a failure is not fatal: the reduce reports it if it needs the ring
+                if (host_io_ == 1 && ctx_[k]) (void)pgt_prepare_host_io(ctx_[k], host_io_bytes_);  // a failure is not fatal: the reduce reports it if it needs the ring
             });
     }
     ~DeviceOpener() {
@@ -761,12 +761,16 @@ class DeviceOpener {
             if (c) pgt_close(c);
     }
     size_t count() const { return ids_.size(); }
-    // the first call decides; get() decides "no" if nobody has said anything by then
-    void plan_host_io(bool wanted) {
+    // the first call decides; get() decides "no" if nobody has said anything by then.  text_bytes: the size of the input text
+    // (an upper bound of the columns parsed from it: below the ring's threshold only the set-up is paid, not the ring); 0 = unknown
+    void plan_host_io(bool wanted, uint64_t text_bytes = 0) {
         if (const char *e = std::getenv("PGT_PREPARE_HOST_IO"); e && std::atoi(e) == 0) wanted = false;  // A/B knob: set-up inside the first reduce, as until round 5
         {
             std::lock_guard<std::mutex> lock(m_);
-            if (host_io_ < 0) host_io_ = wanted ? 1 : 0;
+            if (host_io_ < 0) {
+                host_io_ = wanted ? 1 : 0;
+                host_io_bytes_ = text_bytes;
+            }
         }
         cv_.notify_all();
     }
@@ -785,6 +789,7 @@ class DeviceOpener {
     std::mutex m_;
     std::condition_variable cv_;
     int host_io_ = -1;  // -1 undecided, 0 no, 1 yes
+    uint64_t host_io_bytes_ = 0;
     std::vector<int> ids_;
     std::vector<pgt_ctx *> ctx_;
     std::vector<std::string> err_;

@@ -248,10 +248,11 @@ class Context:
         check(rc, self._ctx)
 
     # ---- host buffers ------------------------------------------------------------------
-    def prepare_host_io(self):
-        """pgt_prepare_host_io: allocate the pinned staging ring of the host-buffer calls below and make the runtime set up its
-        first copies NOW (30 … 90 ms once per process) — worth calling from a thread that opens the device beside a long parse."""
-        self._check(self._lib.pgt_prepare_host_io(self._ctx))
+    def prepare_host_io(self, expected_column_bytes: int = 0):
+        """pgt_prepare_host_io: allocate the pinned staging ring of the host-buffer calls below (unless the expected upload is
+        under 32 MiB; 0 = unknown) and make the runtime set up its first copies NOW (30 … 90 ms once per process) — worth
+        calling from a thread that opens the device beside a long parse."""
+        self._check(self._lib.pgt_prepare_host_io(self._ctx, int(expected_column_bytes)))
 
     def fst_reduce(self, pos, a, b, win) -> np.ndarray:
         pos = np.ascontiguousarray(pos, dtype=np.uint32)

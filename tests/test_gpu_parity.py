@@ -1558,8 +1558,9 @@ def test_host_buffer_calls_through_the_staging_ring_equal_the_device_calls(pgt, 
     assert ctx.fst_reduce(pos[:1000], a[:1000], b[:1000], small).size == small.size   # a small call in between (plain path, workspace reused)
     assert host_rows(ctx) == want                      # again: every buffer of the workspace already large enough
     with pg.Context(0) as c2:                          # a fresh context, prepared up front
-        c2.prepare_host_io()
-        c2.prepare_host_io()                           # idempotent
+        c2.prepare_host_io(1 << 20)                    # a small input announced: the set-up only, no ring yet
+        c2.prepare_host_io()                           # size unknown: the ring; idempotent from here on
+        c2.prepare_host_io(1 << 30)
         assert host_rows(c2) == want
     monkeypatch.setenv("PGT_UPLOAD", "plain")          # round 5's path: hipMemcpy from the caller's pageable columns
     assert host_rows(ctx) == want

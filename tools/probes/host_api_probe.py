@@ -26,7 +26,7 @@ def main():
     ctx = lib.pgt_open(0)
     assert ctx, _lib.last_error()
     if prepare:
-        _lib.check(lib.pgt_prepare_host_io(ctx), ctx)
+        _lib.check(lib.pgt_prepare_host_io(ctx, 0), ctx)
     t_open = time.perf_counter() - t0
     rng = np.random.default_rng(3)
     pos = np.arange(1, n + 1, dtype=np.uint32)
