@@ -502,13 +502,26 @@ int launch_af_np(const AfCols &cols, const uint32_t *pos, uint64_t n, const pgt_
         // so every wave does r tiles.  Measured at 10^8 sites, 8 populations (profiles/r02/af_caps.txt): the
         // unbalanced 2048-workgroup grid of round 1 (12207 tiles over 8192 waves: half the waves do 2 tiles,
         // half 1) 68-69 % of the HBM peak, balanced 74.9 %; caps of 512 / 1024 workgroups 70.8 / 74.0 %.
+        // Round 6: the grid is larger than what is resident at once (one wave per SIMD: 256 workgroups; two: 512), so the
+        // workgroups run in GENERATIONS that end together — and a last generation that is nearly empty idles the chip for a
+        // whole generation (3e8 sites, 8 populations: 1832 workgroups = 7.15 generations of 256, 76 % of the peak where 10^8
+        // sites reach 81 %).  Among the next few round counts the one whose last generation is fullest is taken.
         const uint64_t cap = NP == 2 ? 512 : 2048;
-        const uint64_t max_waves = cap * 4;
-        const uint64_t rounds = (tl.count[1] + max_waves - 1) / max_waves;
+        const bool w1 = NP >= af_one_wave_from();
+        const uint64_t resident = w1 ? 256 : 512, max_waves = cap * 4;
+        const uint64_t r0 = (tl.count[1] + max_waves - 1) / max_waves;
+        uint64_t rounds = r0;
+        double best = -1.0;
+        for (uint64_t r = r0; r < r0 + 4; ++r) {
+            const uint64_t wg = ((tl.count[1] + r - 1) / r + 3) / 4;
+            const uint64_t gens = (wg + resident - 1) / resident;
+            const double fill = (double)wg / (double)(gens * resident);  // 1 = every generation full
+            if (fill > best + 0.02) { best = fill; rounds = r; }           // (a longer round only for a clearly fuller tail)
+        }
         const uint64_t waves = (tl.count[1] + rounds - 1) / rounds;
         uint64_t blocks = (waves + 3) / 4;
         constexpr size_t kStage = (size_t)4 * Shape<NP>::kVals * kAfRadix1 * sizeof(double);  // 4 waves x kAfRadix1 nodes x V doubles
-        if (NP >= af_one_wave_from())
+        if (w1)
             hipLaunchKernelGGL((af_build_kernel_w1<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);
         else
             hipLaunchKernelGGL((af_build_kernel<NP, (NP == 2 ? 4 : 0)>), dim3((unsigned)blocks), dim3(256), kStage, s, cols, n, tl.count[1], tv);

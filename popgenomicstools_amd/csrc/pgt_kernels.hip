@@ -261,7 +261,8 @@ __device__ __forceinline__ void het_count_word(uint32_t w, uint32_t &nonmiss, ui
 // WORKGROUP per level-2 tile, 16 leaf tiles per wave, level 2 summed through LDS so that the tree_up launch
 // disappears: 35 us instead of 30 at 10^8 sites, 0.162 instead of 0.158 ms at 10^9 — fewer, fatter items.)
 constexpr int kHetChunk = 8;
-constexpr uint64_t kHetSmallItems = 30000;  // 8192-site work items (2.5e8 sites) up to which the 128-VGPR build is used
+constexpr uint64_t kHetSmallItems = 18000;  // 8192-site work items (1.5e8 sites) up to which the 128-VGPR build is used (round 6: re-measured
+                                             // under the resident-sized grids, profiles/r06/het_kernel_crossover_ab.md: 1.25e8 sites 32.9 against 34.8 us, 2e8 41.5 against 37.9)
 __device__ __forceinline__ void het_build_body(const int8_t *__restrict__ g, uint64_t n, uint64_t n_items,
                                                const TreeView &tv) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -1875,13 +1876,17 @@ int launch_het(const uint32_t *pos, const int8_t *g, uint64_t n, const pgt_win *
     if (int rc = record(ev_build0, s, err)) return rc;
     if (n > 0) {
         const uint64_t n_items = het_items(n);
-        // short inputs live on many short work items and want the waves (128-VGPR build, 16 waves per CU): 27.4 vs
-        // 29.7 us at 1e8 sites; long ones stream better with the 254-VGPR build: 164 vs 172 us at 1e9 (interleaved
-        // A/B in one process)
+        // short inputs live on many short work items and want the waves (128-VGPR build, 16 waves per CU): 12.7 against 13.7 us
+        // at 3e7 sites, 32.9 against 34.8 at 1.25e8; long ones stream better with the 254-VGPR build: 149 against 172 us at 10^9
+        // (interleaved A/B in one process, profiles/r06/het_kernel_crossover_ab.md)
+        // The grid is what is RESIDENT at once (round 6): 1024 workgroups of the 128-VGPR build (16 waves per CU), 512 of the
+        // 254-VGPR one (8) — until then both took up to 2048, i.e. 1.5 ... 4 generations of workgroups, and a last generation that
+        // is half empty idles half the chip: 10^8 sites 25.0 -> 22.7 us, 3e8 57.6 -> 50.8 (65 -> 74 % of the HBM peak), 10^9
+        // 158.2 -> 152.5 (79 -> 82 %), interleaved A/B (profiles/r06/het_grid_resident_ab.md).
         if (n_items <= kHetSmallItems)
-            hipLaunchKernelGGL(het_build_kernel_w4, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
+            hipLaunchKernelGGL(het_build_kernel_w4, dim3(build_grid(n_items, 1024)), dim3(256), 0, s, g, n, n_items, tv);
         else
-            hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(n_items)), dim3(256), 0, s, g, n, n_items, tv);
+            hipLaunchKernelGGL(het_build_kernel, dim3(build_grid(n_items, 512)), dim3(256), 0, s, g, n, n_items, tv);
         if (int rc = hip_fail(hipGetLastError(), "het_build_kernel", err)) return rc;
         if (int rc = launch_upper<NodeHet>(tl, tv, 1, s, err, 1, n_items * kHetChunk)) return rc;
     }
