@@ -124,11 +124,21 @@ int workspace(pgt_ctx *ctx, int kind, size_t bytes, void **out) {
 int ring_prepare(pgt_ctx *ctx) {
     HostIo &io = ctx->io;
     if (io.ring_ready) return PGT_OK;
-    if (const char *e = std::getenv("PGT_UPLOAD_WORKERS")) io.workers = std::min(std::max(std::atoi(e), 1), (int)HostIo::kMaxWorkers);
-    if (const char *e = std::getenv("PGT_UPLOAD_CHUNK_MIB")) io.chunk = (size_t)std::min(std::max(std::atoi(e), 1), 64) << 20;
-    for (int s = 0; s < 2 * io.workers; ++s) {
-        if (int rc = hip_check(ctx, hipHostMalloc(reinterpret_cast<void **>(&io.pin[s]), io.chunk, hipHostMallocDefault), "upload ring: hipHostMalloc")) return rc;
-        if (int rc = hip_check(ctx, hipEventCreateWithFlags(&io.slot_done[s], hipEventDisableTiming), "upload ring: hipEventCreate")) return rc;
+    if (!io.pin[0]) {  // the geometry is fixed by the first attempt
+        if (const char *e = std::getenv("PGT_UPLOAD_WORKERS")) io.workers = std::min(std::max(std::atoi(e), 1), (int)HostIo::kMaxWorkers);
+        if (const char *e = std::getenv("PGT_UPLOAD_CHUNK_MIB")) io.chunk = (size_t)std::min(std::max(std::atoi(e), 1), 64) << 20;
+    }
+    for (int s = 0; s < 2 * io.workers; ++s) {  // (a slot that exists already: an earlier attempt failed further on)
+        if (!io.pin[s])
+            if (int rc = hip_check(ctx, hipHostMalloc(reinterpret_cast<void **>(&io.pin[s]), io.chunk, hipHostMallocDefault), "upload ring: hipHostMalloc")) {
+                io.pin[s] = nullptr;
+                return rc;
+            }
+        if (!io.slot_done[s])
+            if (int rc = hip_check(ctx, hipEventCreateWithFlags(&io.slot_done[s], hipEventDisableTiming), "upload ring: hipEventCreate")) {
+                io.slot_done[s] = nullptr;
+                return rc;
+            }
     }
     io.ring_ready = true;
     return PGT_OK;
@@ -208,7 +218,13 @@ int upload_columns(pgt_ctx *ctx, UploadJob *jobs, int n_jobs, ApiTrace &trace) {
     };
     std::vector<std::thread> th;
     const int n_workers = (int)std::min<size_t>((size_t)io.workers, pieces.size());
-    for (int w = 1; w < n_workers; ++w) th.emplace_back(worker, w);
+    for (int w = 1; w < n_workers; ++w) {
+        try {
+            th.emplace_back(worker, w);
+        } catch (...) {  // no thread to be had: the workers that exist (at least this one) take all pieces
+            break;
+        }
+    }
     worker(0);
     for (auto &t : th) t.join();
     const hipError_t sync = hipStreamSynchronize(io.copy_stream);
