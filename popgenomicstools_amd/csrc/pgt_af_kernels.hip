@@ -170,16 +170,18 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 // BURST > 0: one column at a time (pgt_kernels.hip: fst_build_kernel) — per group of BURST pieces each column's BURST
 // kibibytes are requested and awaited in turn.  Taken for TWO populations only (BURST = 4: 77.7 -> 85.3 % of the HBM peak
 // at 10^9 sites, 74.0 -> 75.6 % at 10^8); with 4 and 8 populations the piece-by-piece form below wins (8 populations: 78.2
-// against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt): there the kernel is bound by
-// its node stores and its arithmetic, and 4 x 8 column registers cost the prefetch of the next piece.
+// against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt; again in round 6 at one wave per
+// SIMD: 58.7 ... 61.9 % against 80.5, profiles/r06/af8_variants_ab_6_bursts_and_grid.md): 8 columns a burst each leave every
+// column's queue empty seven eighths of the time.
 template <int NP, int BURST>
 __device__ __forceinline__ void af_build_body(const AfCols &cols, uint64_t n, uint64_t n_l2, const AfTree &tv) {
     constexpr int V = Shape<NP>::kVals;
 
     const int lane = threadIdx.x & (kWave - 1);
-    // the wave's index, SAID to be wave-uniform (readfirstlane): tile base, rotation and every column address are then scalar
-    // registers and a load is `global_load_dwordx4 v, v_lane_offset, s[base]` — with the index derived from threadIdx the
-    // compiler carried 64-bit per-lane addresses for all 8 columns (91 v_lshl_add_u64 per two pieces, 16+ VGPRs)
+    // the wave's index, SAID to be wave-uniform (readfirstlane): tile base and rotation are then scalar registers and the only
+    // per-lane part of an address is the lane's 16 bytes — with the index derived from threadIdx the compiler computed 64-bit
+    // per-lane addresses for every load (91 v_lshl_add_u64 per leaf; 16 now: it still keeps `column + lane bytes` in vector
+    // registers rather than use the scalar-base form of the load)
     const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int my = rs_my_index<V>(lane);
