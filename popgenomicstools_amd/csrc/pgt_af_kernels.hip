@@ -171,8 +171,7 @@ __device__ __forceinline__ double *af_node(const AfTree &tv, int level_slot, int
 // kibibytes are requested and awaited in turn.  Taken for TWO populations only (BURST = 4: 77.7 -> 85.3 % of the HBM peak
 // at 10^9 sites, 74.0 -> 75.6 % at 10^8); with 4 and 8 populations the piece-by-piece form below wins (8 populations: 78.2
 // against 76.5 % at 10^9, 73.1 against 69.1 % at 10^8; profiles/r03/af_column_bursts_ab.txt; again in round 6 at one wave per
-// SIMD: 58.7 ... 61.9 % against 80.5, profiles/r06/af8_variants_ab_6_bursts_and_grid.md): 8 columns a burst each leave every
-// column's queue empty seven eighths of the time.
+// SIMD: 58.7 ... 61.9 % against 80.5, profiles/r06/af8_variants_ab_6_bursts_and_grid.md).
 template <int NP, int BURST>
 __device__ __forceinline__ void af_build_body(const AfCols &cols, uint64_t n, uint64_t n_l2, const AfTree &tv) {
     constexpr int V = Shape<NP>::kVals;
