@@ -162,7 +162,9 @@ class Phases:
                          + (" — degrading to the result secured before it" if degradable else " — giving up (exit 124)"))
                 if degradable:
                     if self.rank == 0 and self.secured is not None:
-                        print(self.secured(f"phase '{name}' exceeded its deadline of {self.deadline_of(name):.0f} s"), flush=True)
+                        line = self.secured(f"phase '{name}' exceeded its deadline of {self.deadline_of(name):.0f} s")
+                        sys.stdout.flush()
+                        os.write(stdout_to_stderr.real_fd if stdout_to_stderr.real_fd is not None else 1, (line + "\n").encode())
                     os._exit(0)
                 os._exit(124)
 
@@ -194,6 +196,33 @@ class _Phase:
         dt = time.perf_counter() - self.t0
         ph.taken[self.name] = ph.taken.get(self.name, 0.0) + dt
         ph.say(f"{self.name}: {'FAILED (' + et.__name__ + ')' if et else 'done'} in {dt:.2f} s")
+        return False
+
+
+class stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration: gloo and RCCL print their banners ("[Gloo] Rank 0 is connected …", "RCCL version : …")
+    with C stdio on STDOUT, where this script owes exactly ONE line, the JSON.  libc's buffers are flushed before the descriptor is
+    given back, so nothing written meanwhile can surface on stdout later."""
+
+    real_fd = None  # the process' real stdout while a redirection is in force (the watchdog's secured line goes THERE)
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        stdout_to_stderr.real_fd = self.saved
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        stdout_to_stderr.real_fd = None
+        os.close(self.saved)
         return False
 
 
@@ -826,7 +855,7 @@ def main():
     telemetry = {"reader": tel.describe(), "at_start": tel.snapshot()} if tel else {}
     group, coll_dev, backend_desc = None, dev, "none (single GPU)"
     if world > 1:
-        with ph("init"):
+        with ph("init"), stdout_to_stderr():
             group, coll_dev, backend_desc = bring_up_collectives(world, rank, dev, ph)
         ph.say("collectives: " + backend_desc)
 
@@ -1148,7 +1177,7 @@ def main():
             # without this leg (exit 0) instead of losing the run
             ph.secure(lambda why: assemble(runs, build_avg, query_avg, dict(extra, exchange_overhead={"available": False, "why": why},
                                                                              telemetry=telemetry), cpu, ref_check=ref_check))
-            with ph("exchange overhead", degradable=True):
+            with ph("exchange overhead", degradable=True), stdout_to_stderr():
                 try:
                     extra["exchange_overhead"] = exchange_overhead(ctx, dev, dev_index, (pos, a, b), win, tree, W, S, ph, steps=args.exchange_steps)
                 except Exception as e:  # noqa: BLE001 — RCCL absent / refused: reported, the headline stands

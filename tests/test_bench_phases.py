@@ -203,3 +203,32 @@ def test_telemetry_reader_degrades_to_nothing_and_summarises_samples():
     assert out["sysfs_sclk_mhz"]["median"] == 2350
     assert out["residency_growth"] == {"ppt_residency_acc": 300, "accumulation_counter": 1000}
     assert g._Sampler(t, 1.0).summary() == {"samples": 0}
+
+
+def test_library_banners_do_not_reach_stdout_and_the_secured_line_still_does():
+    """gloo and RCCL print banners on stdout with C stdio; bench.py owes stdout ONE line.  stdout_to_stderr() sends file descriptor 1
+    to 2 for the duration (C-level writes included) — and a degradable phase that overruns INSIDE it still puts its secured line on
+    the process' real stdout."""
+    r = _run("""
+        import os, ctypes
+        libc = ctypes.CDLL(None)
+        with bench.stdout_to_stderr():
+            libc.puts(b"BANNER from C stdio")           # what RCCL does
+            os.write(1, b"BANNER from a raw write\\n")
+            print("BANNER from python")
+        print("the one line", flush=True)
+    """)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines() == ["the one line"], r.stdout
+    assert r.stderr.count("BANNER") == 3
+    r = _run("""
+        ph = bench.Phases(rank=0, world=1, scale=0.1)       # 'exchange overhead': 120 s x 0.1 = 12 s, rank 0 fires 3 s early
+        ph.secure(lambda why: json.dumps({"secured": True, "why": why}))
+        with ph("exchange overhead", degradable=True), bench.stdout_to_stderr():
+            print("BANNER")
+            time.sleep(60)
+    """)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["secured"] is True, r.stdout
+    assert "BANNER" in r.stderr
