@@ -286,7 +286,7 @@ def checker_tools():
     return oracle_bind
 
 
-def check_rows_against_tsv(tsv_path, table, win, n_sample, against, row_dtype=None, value="fst", count="n"):
+def check_rows_against_tsv(tsv_path, table, win, n_sample, against, row_dtype=None, value="fst", count="n", first_site=0):
     """The LIVE parity check of a timed run (fstWindow.cpp:69-107,150-152; hetWindow.cpp:66-105,148-150): the reference's TSV
     for the first n_sample sites against the rows the GPU produced for the whole genome in the timed run.  Comparable are
     the windows that end inside the sample (the streaming machine emits them before it can know what follows); what the
@@ -294,18 +294,31 @@ def check_rows_against_tsv(tsv_path, table, win, n_sample, against, row_dtype=No
     exact; the statistic as printed (`%g`), or — on a rounding boundary of the six printed digits — printed from a value
     within 1e-9 relative.  row_dtype / value / count: FST rows (`fst`, `n`) by default; het rows are (`h`, `nonmissing`)."""
     rows = np.frombuffer(table.tobytes(), dtype=row_dtype or FST_ROW_DTYPE)[:win.size]  # pair 0 = the first table
-    k = int(np.count_nonzero(win["hi"] <= n_sample))
-    assert np.all(win["hi"][:k] <= n_sample), "windows ending inside the sample are a prefix of the table"
     with open(tsv_path) as fh:
         ref_lines = fh.read().splitlines()
-    res = {"against": against, "windows": k, "reference_rows": len(ref_lines), "equal": False}
-    if len(ref_lines) < k:
-        res["mismatch"] = f"the reference printed {len(ref_lines)} rows, the GPU table has {k} windows ending inside the sample"
-        return res
+    if first_site:
+        # a TAIL sample (sites [first_site, n) with first_site a chromosome start): a machine started there emits exactly the
+        # full run's windows that begin at or behind first_site (those in front of it carry sites of the previous chromosome,
+        # SURVEY Q1), up to and including the end-of-file rule (Q2) — every reference row must have its window
+        at = int(np.count_nonzero(win["lo"] < first_site))
+        assert np.all(win["lo"][at:] >= first_site), "windows beginning inside the tail sample are a suffix of the table"
+        k = int(win.size - at)
+        res = {"against": against, "windows": k, "reference_rows": len(ref_lines), "equal": False}
+        if len(ref_lines) != k:
+            res["mismatch"] = f"the reference printed {len(ref_lines)} rows for the tail sample, the GPU table has {k} windows beginning inside it"
+            return res
+    else:
+        at = 0
+        k = int(np.count_nonzero(win["hi"] <= n_sample))
+        assert np.all(win["hi"][:k] <= n_sample), "windows ending inside the sample are a prefix of the table"
+        res = {"against": against, "windows": k, "reference_rows": len(ref_lines), "equal": False}
+        if len(ref_lines) < k:
+            res["mismatch"] = f"the reference printed {len(ref_lines)} rows, the GPU table has {k} windows ending inside the sample"
+            return res
     rounding_boundary = 0
     for i in range(k):
-        r = rows[i]
-        want = ["chr%d" % (int(win["label_run"][i]) + 1), str(int(r["start"])), str(int(r["end"])), str(int(r["mid"])), None, str(int(r[count]))]
+        r = rows[at + i]
+        want = ["chr%d" % (int(win["label_run"][at + i]) + 1), str(int(r["start"])), str(int(r["end"])), str(int(r["mid"])), None, str(int(r[count]))]
         got = ref_lines[i].split("\t")
         f = float(r[value])
         ok = len(got) == 6 and all(w is None or w == g for w, g in zip(want, got))
@@ -377,6 +390,25 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
     ref = oracle_bind.ref_binary("fstWindow")
     kind = "reference" if ref else "port"
     timing = {}
+    # A second sample, NOT timed: the genome's last chromosomes (about n_sample sites), run beside the first on another core — its
+    # TSV covers what the head sample cannot: the last windows of the genome and the end-of-file rule (fstWindow.cpp:150-152)
+    n_all = int(a.numel())
+    starts = genome.chr_start[genome.chr_start >= max(n_all - n_sample, n_sample)]
+    tail_from = int(starts[0]) if (table is not None and starts.size and int(starts[0]) < n_all) else 0
+    path_t, tsv_t = os.path.join(tmpdir, "tail.fst.txt"), os.path.join(tmpdir, "tail.windows.tsv")
+    if tail_from:
+        orc.write_fst_text(path_t, genome.chr_ids_np(tail_from, n_all), pos[tail_from:].cpu().numpy().view(np.uint32),
+                           a[tail_from:].cpu().numpy(), b[tail_from:].cpu().numpy())
+
+    def tail_run():
+        try:
+            if ref:
+                with open(tsv_t, "w") as out_fh:
+                    subprocess.run([ref, path_t, str(W), str(S)], stdout=out_fh, check=True)
+            else:
+                assert orc.fst_text(path_t, W, S, tsv_t) == 0
+        except BaseException as e:  # noqa: BLE001
+            timing["tail_error"] = e
 
     def cpu_run():
         t0 = time.perf_counter()
@@ -392,12 +424,19 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
 
     import threading
     th = threading.Thread(target=cpu_run)
+    th_tail = threading.Thread(target=tail_run) if tail_from else None
     th.start()
+    if th_tail:
+        th_tail.start()
     if beside is not None:
         beside(lambda: not th.is_alive())
     th.join()
+    if th_tail:
+        th_tail.join()
     if "error" in timing:
         raise timing["error"]
+    if "tail_error" in timing:
+        raise timing["tail_error"]
     dt = timing["dt"]
     if ctx is not None and extra is not None:
         # the same text through the device-side ingest (pgt_ingest_text): the parsed columns must equal the resident ones
@@ -423,15 +462,25 @@ def cpu_baseline(pos, a, b, genome, W, S, n_sample, ctx=None, extra=None, beside
         rows_check = check_rows_against_tsv(tsv, table, win, n_sample,
                                             "reference fstWindow (oracle/_ref/fstWindow, the unmodified reference source compiled)" if ref
                                             else "oracle port (oracle/liboracle.so; the reference binary did not travel)")
-    os.unlink(path)
-    os.unlink(tsv)
+        if tail_from:
+            tail = check_rows_against_tsv(tsv_t, table, win, n_all, rows_check["against"], first_site=tail_from)
+            rows_check["tail"] = {"sites": f"[{tail_from}, {n_all}): the last {n_all - tail_from} sites (the last chromosomes), the reference run beside "
+                                           "the timed one on another core", **{k_: v_ for k_, v_ in tail.items() if k_ != "against"}}
+            rows_check["windows"] += tail["windows"]
+            rows_check["reference_rows"] += tail["reference_rows"]
+            if not tail["equal"]:
+                rows_check["equal"] = False
+                rows_check["mismatch"] = "tail sample: " + tail.get("mismatch", "?")
+    for f_ in (path, tsv, path_t, tsv_t):
+        if os.path.exists(f_):
+            os.unlink(f_)
     os.rmdir(tmpdir)
     return {"value": n_sample / dt, "unit": "sites/s", "cores": 1, "kind": kind,
             "sample": f"first {n_sample} sites of the workload as text ({'oracle/_ref/fstWindow' if ref else 'oracle port'} "
                       f"{W} {S}, parse included, stdout to a file, {dt:.2f} s); host has {os.cpu_count()} logical cores, "
                       f"the reference is single-threaded",
-            "beside": ("the sustained GPU leg ran on another host thread meanwhile (one core launching kernels)" if beside is not None
-                       else "nothing")}, rows_check
+            "beside": (("the sustained GPU leg ran on another host thread meanwhile (one core launching kernels)" if beside is not None
+                        else "nothing") + ("; a second, untimed reference run (the tail sample of rows_check) on another core" if tail_from else ""))}, rows_check
 
 
 def timed_config(ctx, call, alg_bytes, reps=15):

@@ -169,6 +169,13 @@ def test_rows_check_compares_fst_and_het_rows_with_a_reference_tsv(tmp_path):
     tsv.write_text("\n".join(lines[:2]) + "\n")
     res = bench.check_rows_against_tsv(str(tsv), rows.view(np.uint8), win, 40, "a reference")
     assert res["equal"] is False and "2 rows" in res["mismatch"]
+    # a TAIL sample: the windows that begin at or behind `first_site` against ALL rows the reference printed for that sample
+    tsv.write_text("\n".join(lines[2:3] + ["chr2\t31\t60\t45\t0.5\t30"]) + "\n")
+    res = bench.check_rows_against_tsv(str(tsv), rows.view(np.uint8), win, 60, "a reference", first_site=20)
+    assert res["equal"] is True and res["windows"] == 2 and res["reference_rows"] == 2
+    tsv.write_text(lines[2] + "\n")  # the reference printed one row less than the table has windows there: not a pass
+    res = bench.check_rows_against_tsv(str(tsv), rows.view(np.uint8), win, 60, "a reference", first_site=20)
+    assert res["equal"] is False and "tail sample" in res["mismatch"]
     # het rows: the value is h, the count column is `nonmissing` (hetWindow.cpp:87)
     h = np.zeros(4, dtype=HET_ROW_DTYPE)
     h["start"], h["end"], h["mid"], h["nonmissing"], h["nhet"] = rows["start"], rows["end"], rows["mid"], [18, 20, 0, 5], [9, 5, 0, 1]
