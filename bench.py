@@ -50,7 +50,11 @@ The default N=1 run also times BASELINE configs 2, 3 and 5 in their one-GPU form
 bounded sample ("cpu_baseline").  That leg is also the run's LIVE PARITY CHECK: the TSV the reference prints for the
 sample (the first 5x10^7 sites = the first two chromosomes, ~5000 windows) is compared with the rows the timed GPU run
 produced for those windows — "rows_check": {"against": "reference fstWindow ...", "windows": k, "equal": true}; a mismatch
-gives "ok": false and exit code 3.  Prints ONE JSON line on rank 0.
+gives "ok": false and exit code 3.  Round 6: the same check on the genome's LAST chromosomes (a second, untimed reference run beside
+the timed one: the last windows and the end-of-file rule), a check of configs[2]'s het rows against the reference hetWindow
+("extra.dxy_het_fused_1e8.rows_check"), the per-step cost of the multi-GPU row exchange priced on this one GPU
+("extra.exchange_overhead") and the card's identity and telemetry ("extra.telemetry").  Prints ONE JSON line on rank 0 — and nothing
+else on stdout (gloo's and RCCL's banners are sent to stderr).
 """
 import argparse
 import hashlib
