@@ -283,8 +283,8 @@ def fmt_g6(x):
 
 def checker_tools():
     """oracle/ (test infrastructure): the text writers, the compiled reference binaries under oracle/_ref and the CPU port.
-    bench.py uses them in exactly two places, both outside every timed region: cpu_baseline (the reported CPU number + the live
-    parity check of the headline rows) and het_rows_check (the live parity check of configs[2]).  Never on the measured path."""
+    bench.py uses them in exactly three places, all outside every timed region: cpu_baseline (the reported CPU number + the live
+    parity check of the headline rows), het_rows_check (configs[2]) and pair_rows_check (configs[4]).  Never on the measured path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind
     return oracle_bind
@@ -339,6 +339,37 @@ def check_rows_against_tsv(tsv_path, table, win, n_sample, against, row_dtype=No
     res[value + "_on_a_rounding_boundary"] = rounding_boundary
     res["tsv_sha256"] = hashlib.sha256("\n".join(ref_lines[:k]).encode()).hexdigest()
     return res
+
+
+def pair_rows_check(g8, pos, a, b, pair_table, win_h, W, S, pair, n_sample=20_000_000):
+    """configs[4]'s live reference check (one-GPU form): the UNMODIFIED reference fstWindow on the first n_sample sites of ONE of the 28
+    batched pairs (its `a`, `b` columns as text, ~4 s of the CPU tool, outside every timed region) against that pair's table of the
+    batched call — that `grid.y` = pair p really reduced pair p's columns into table p (fstWindow.cpp:69-107)."""
+    oracle_bind = checker_tools()
+    ref = oracle_bind.ref_binary("fstWindow")
+    orc = oracle_bind.load()
+    tmpdir = tempfile.mkdtemp(prefix="pgt_bench_pair_")
+    path, tsv = os.path.join(tmpdir, "sample.fst.txt"), os.path.join(tmpdir, "sample.fst.tsv")
+    try:
+        orc.write_fst_text(path, g8.chr_ids_np(0, n_sample), pos[:n_sample].cpu().numpy().view(np.uint32), a[:n_sample].cpu().numpy(),
+                           b[:n_sample].cpu().numpy())
+        t0 = time.perf_counter()
+        if ref:
+            with open(tsv, "w") as out_fh:
+                subprocess.run([ref, path, str(W), str(S)], stdout=out_fh, check=True, timeout=300)
+        else:
+            assert orc.fst_text(path, W, S, tsv) == 0
+        dt = time.perf_counter() - t0
+        res = check_rows_against_tsv(tsv, pair_table, win_h, n_sample,
+                                     "reference fstWindow (oracle/_ref/fstWindow, the unmodified reference source compiled)" if ref
+                                     else "oracle port (oracle/liboracle.so; the reference binary did not travel)")
+        res["sample"] = f"first {n_sample} sites of pair {pair} of 28 as text, {dt:.2f} s of the CPU tool"
+        return res
+    finally:
+        for f_ in (path, tsv):
+            if os.path.exists(f_):
+                os.unlink(f_)
+        os.rmdir(tmpdir)
 
 
 def het_rows_check(g8, pos, g1, het_table, win_h, W, S, n_sample=20_000_000):
@@ -599,6 +630,11 @@ def extra_configs(ctx, dev, W, S, tree_pool, check_het=True):
     r["sites_per_s"] = n8 / (r["ms_per_step"] * 1e-3)
     out["pairs28_1e8"] = dict(r, config="BASELINE configs[4], one-GPU form: fstWindow 28 pop-pairs x 1e8 sites batched",
                               kernel="fst_build_kernel (grid.y = 28)")
+    if check_het:  # (the same switch: --no-cpu runs skip every leg that needs the CPU tools)
+        torch.cuda.synchronize()
+        p_ = 17
+        tbl = rows[p_ * nw * FST_ROW_DTYPE.itemsize: (p_ + 1) * nw * FST_ROW_DTYPE.itemsize].cpu().numpy()
+        out["pairs28_1e8"]["rows_check"] = pair_rows_check(g8, pos, al[p_], bl[p_], tbl, win_h, W, S, p_)
     del al, bl
     # ihsWindow-style extreme-score scan: one f64 score column, 100 kb windows
     from popgenomicstools_amd._lib import EXT_ROW_DTYPE, PGT_EXT_IHS
@@ -1136,7 +1172,8 @@ def main():
             "data": "synthetic",
             # every transport that ran delivered the single-GPU table (or was not verifiable by request)
             "ok": (all(r["verified"] is not False for r in usable) and (ref_check is None or bool(ref_check["equal"])) and not degraded
-                   and bool(extra.get("dxy_het_fused_1e8", {}).get("rows_check", {"equal": True})["equal"])),
+                   and bool(extra.get("dxy_het_fused_1e8", {}).get("rows_check", {"equal": True})["equal"])
+                   and bool(extra.get("pairs28_1e8", {}).get("rows_check", {"equal": True})["equal"])),
             "degraded": degraded,
             "config": {"workload": (f"fstWindow 2 pops x {n_total:.0e} sites total" if not pairs_mode else
                                     f"fstWindow all {n_tables} pairs of 8 populations x {n_total:.0e} sites total, one batched call per step,")
@@ -1252,6 +1289,11 @@ def main():
     het_check = extra.get("dxy_het_fused_1e8", {}).get("rows_check") if isinstance(extra, dict) else None
     if het_check is not None and not het_check["equal"]:  # configs[2]: the fused kernel's het rows differ from the reference's TSV
         print("bench.py: het rows of the fused dxy + het run DIFFER from the reference hetWindow's TSV: " + het_check.get("mismatch", "?"),
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    pair_check = extra.get("pairs28_1e8", {}).get("rows_check") if isinstance(extra, dict) else None
+    if pair_check is not None and not pair_check["equal"]:  # configs[4]: a pair's table of the batched call differs from the reference's TSV
+        print("bench.py: rows of pair 17 of the batched 28-pair run DIFFER from the reference fstWindow's TSV: " + pair_check.get("mismatch", "?"),
               file=sys.stderr, flush=True)
         sys.exit(3)
     if world > 1:

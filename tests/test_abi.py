@@ -100,11 +100,11 @@ def test_only_tests_smoke_and_bench_touch_the_oracle():
                     text = open(os.path.join(root, f), errors="ignore").read()
                     assert "oracle_bind" not in text and "liboracle" not in text and "window_oracle" not in text, os.path.join(root, f)
     bench_src = open(os.path.join(ROOT, "bench.py")).read()
-    # ONE import, inside checker_tools(); that function is called by the CPU-baseline leg and by the configs[2] rows check only
+    # ONE import, inside checker_tools(); that function is called by the CPU-baseline leg and by the configs[2] / configs[4] rows checks only
     assert bench_src.count("import oracle_bind") == 1 and "def cpu_baseline" in bench_src
     tools_at = bench_src.index("def checker_tools")
     assert tools_at < bench_src.index("import oracle_bind") < bench_src.index("def check_rows_against_tsv")
     import re
     callers = [bench_src.rfind("\ndef ", 0, m.start()) for m in re.finditer(r"= checker_tools\(\)", bench_src)]
     names = sorted(re.match(r"\ndef (\w+)", bench_src[c:]).group(1) for c in callers)
-    assert names == ["cpu_baseline", "het_rows_check"], names
+    assert names == ["cpu_baseline", "het_rows_check", "pair_rows_check"], names
