@@ -584,7 +584,12 @@ def _af_rows(ctx, pos, freqs, nsamp, win):
 
 @pytest.mark.parametrize("n_pops,n,W,S", [(2, 1, 1, 1), (2, 127, 50, 7), (2, 300_000, 50_000, 10_000), (3, 8193, 1000, 1000),
                                           (4, 129, 128, 1), (5, 70_000, 9_000, 4_000), (8, 16_385, 5_000, 2_500),
-                                          (8, 700_001, 50_000, 10_000), (8, 1_200_000, 600_000, 300_000)])
+                                          (8, 700_001, 50_000, 10_000), (8, 1_200_000, 600_000, 300_000),
+                                          # round 6 (512-site leaf nodes, ragged sites read as 16-byte pairs, the column's last site alone):
+                                          # column lengths around a leaf, a level-2 tile and odd ends, windows sliding by ONE site so that
+                                          # every offset of a window's ends inside a pair and inside a leaf occurs
+                                          (8, 511, 300, 1), (8, 512, 257, 1), (8, 513, 512, 1), (3, 1025, 513, 1), (8, 8191, 2000, 1),
+                                          (2, 8193, 1030, 1), (8, 9217, 4100, 3), (5, 24_577, 8192, 37)])
 def test_af_front_end_vs_oracle(pgt, ctx, oracle, n_pops, n, W, S):
     """All pairs from the frequency columns == fstWindow (oracle, sequential sums) run on the (a, a+b)
     columns that the literal restatement of WCFst() produces for that pair."""
